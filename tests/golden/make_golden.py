@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING THE REFERENCE (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Needs /root/reference (read-only); writes tests/golden/*.npz.  The reference never
+travels to the GPU box - only these outputs do.  Inputs and weights are regenerated
+procedurally (depth_image_captioning_pub_amd/synthetic.py) from the seeds below, so the
+fixtures hold OUTPUTS only (large tensors as a strided subsample + sum + L2 norm).
+
+Reference classes exercised (paths relative to /root/reference):
+  Captioning_models/attention.py: Soft_Attention, Hard_Attention
+  Captioning_models/Depth_caption_model/depth_models.py:
+      Depth_CNN_endoder, CD_RNNDecoderWithSoftAttention, CD_RNNDecoderWithHardAttention
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.utils.rnn import pack_padded_sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from Captioning_models.attention import Soft_Attention  # noqa: E402  (reference)
+from Captioning_models.Depth_caption_model.depth_models import (  # noqa: E402  (reference)
+    CD_RNNDecoderWithHardAttention, CD_RNNDecoderWithSoftAttention, Depth_CNN_endoder)
+
+from depth_image_captioning_pub_amd import synthetic as syn  # noqa: E402
+
+SUB = 61           # subsample stride for large tensors
+BIG = 1 << 16      # tensors above this many elements are stored subsampled
+
+
+def pack(t: torch.Tensor, name: str, out: dict) -> None:
+    a = t.detach().cpu().contiguous().numpy()
+    if a.size <= BIG:
+        out[name] = a
+    else:
+        flat = a.reshape(-1)
+        out[name + "__sub"] = flat[::SUB].copy()
+        out[name + "__sum"] = np.float64(flat.astype(np.float64).sum())
+        out[name + "__l2"] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        out[name + "__shape"] = np.asarray(a.shape, np.int64)
+
+
+class FixedDropout(nn.Module):
+    """Stands in for decoder.dropout so the mask is an explicit input (quirk Q6):
+    same arithmetic as nn.Dropout in train mode, h * (keep / (1-p))."""
+
+    def __init__(self, mult):
+        super().__init__()
+        self.mult, self.t = mult, 0
+
+    def forward(self, h):
+        m = self.mult[: h.shape[0], self.t]
+        self.t += 1
+        return h * m
+
+
+class RandFeeder:
+    """Replaces torch.rand inside Gumbel_softmax (attention.py:17,40) with prepared draws."""
+
+    def __init__(self, u):
+        self.u, self.t = u, 0
+
+    def __call__(self, bs, k):
+        r = self.u[self.t, :bs]
+        self.t += 1
+        return r.clone()
+
+
+def case_decoder(tag, lengths, vocab, seed, train, hard=False):
+    out = {}
+    B = len(lengths)
+    w = syn.decoder_weights(vocab, seed=seed)
+    f_rgb = syn.features(B, seed + 1, replicate=True)
+    f_dep = syn.features(B, seed + 2, replicate=True, scale=0.5)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=seed)
+    tmax = max(lens) - 1
+    if hard:
+        dec = CD_RNNDecoderWithHardAttention(128, 128, 2048, 128, vocab, "cpu", 0.5)
+    else:
+        dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    dec.load_state_dict(w)
+    f_rgb = f_rgb.clone().requires_grad_(True)
+    f_dep = f_dep.clone().requires_grad_(True)
+    if train:
+        dec.train()
+        dec.dropout = FixedDropout(syn.dropout_multiplier(B, tmax, 0.5, seed=seed))
+    else:
+        dec.eval()
+    real_rand = torch.rand
+    if hard:
+        u = syn.gumbel_uniforms(tmax, B, seed=seed)
+        torch.rand = RandFeeder(u)
+        temp = torch.tensor(0.8)
+    try:
+        if hard:
+            packed = dec(f_rgb, f_dep, caps, lens, temp)
+            alphas = None
+        else:
+            packed, alphas = dec(f_rgb, f_dep, caps, lens)
+    finally:
+        torch.rand = real_rand
+    dec_len = [l - 1 for l in lens]
+    targets = pack_padded_sequence(caps[:, 1:], dec_len, batch_first=True)
+    loss = F.cross_entropy(packed.data, targets.data, ignore_index=syn.special_token_ids(vocab)["<null>"])
+    if alphas is not None:
+        loss = loss + 0.7 * ((1.0 - alphas.sum(dim=1)) ** 2).mean()      # depth_train.py:214-216
+    out["batch_sizes"] = packed.batch_sizes.numpy().astype(np.int64)
+    pack(packed.data, "logits", out)
+    if alphas is not None:
+        pack(alphas, "alphas", out)
+    out["loss"] = np.float32(loss.item())
+    out["argmax"] = packed.data.argmax(dim=1).numpy().astype(np.int64)
+    if train:
+        opt = torch.optim.AdamW(dec.parameters(), lr=1e-3)                 # depth_train.py:136-137
+        opt.zero_grad()
+        loss.backward()
+        for k, p in dec.named_parameters():
+            pack(p.grad, "grad." + k, out)
+        pack(f_rgb.grad, "grad.features", out)
+        pack(f_dep.grad, "grad.depth_features", out)
+        opt.step()
+        for k, p in dec.named_parameters():
+            pack(p, "adamw1." + k, out)
+    np.savez_compressed(os.path.join(HERE, f"decoder_{tag}.npz"), **out)
+    print(tag, "loss", out["loss"], "N", int(packed.data.shape[0]))
+
+
+def case_decoder_hard_eval(tag, lengths, vocab, seed):
+    out = {}
+    B = len(lengths)
+    w = syn.decoder_weights(vocab, seed=seed)
+    f_rgb = syn.features(B, seed + 1)
+    f_dep = syn.features(B, seed + 2, scale=0.5)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=seed)
+    tmax = max(lens) - 1
+    dec = CD_RNNDecoderWithHardAttention(128, 128, 2048, 128, vocab, "cpu", 0.5)
+    dec.load_state_dict(w)
+    dec.eval()
+    real_rand = torch.rand
+    torch.rand = RandFeeder(syn.gumbel_uniforms(tmax, B, seed=seed))
+    try:
+        packed = dec.eval_forward(f_rgb, f_dep, caps, lens)
+    finally:
+        torch.rand = real_rand
+    pack(packed.data, "logits", out)
+    out["batch_sizes"] = packed.batch_sizes.numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, f"decoder_{tag}.npz"), **out)
+    print(tag, "ok")
+
+
+def case_adamw3(vocab=50, seed=31):
+    """Three optimiser steps on the same batch (post-step weights after step 3)."""
+    out = {}
+    lengths = [9, 7, 7, 4, 3]
+    B = len(lengths)
+    w = syn.decoder_weights(vocab, seed=seed)
+    f_rgb = syn.features(B, seed + 1)
+    f_dep = syn.features(B, seed + 2, scale=0.5)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=seed)
+    dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    dec.load_state_dict(w)
+    dec.eval()                                                   # dropout off; optimiser still steps
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        packed, alphas = dec(f_rgb, f_dep, caps, lens)
+        tg = pack_padded_sequence(caps[:, 1:], [l - 1 for l in lens], batch_first=True)
+        loss = F.cross_entropy(packed.data, tg.data) + 0.7 * ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    out["losses"] = np.asarray(losses, np.float32)
+    for k, p in dec.named_parameters():
+        pack(p, "adamw3." + k, out)
+    np.savez_compressed(os.path.join(HERE, "decoder_adamw3.npz"), **out)
+    print("adamw3", losses)
+
+
+def case_soft_attention(seed=11):
+    out = {}
+    w = syn.decoder_weights(50, seed=seed)
+    att = Soft_Attention(2048, 128, 128)
+    att.load_state_dict({k[len("attention."):]: v for k, v in w.items() if k.startswith("attention.")})
+    feats = syn.features(3, seed + 1, replicate=False)
+    h = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 2)).standard_normal((3, 128)).astype(np.float32))
+    ctx, alpha = att(feats, h)
+    pack(ctx, "ctx", out)
+    pack(alpha, "alpha", out)
+    np.savez_compressed(os.path.join(HERE, "soft_attention.npz"), **out)
+    print("soft_attention ok")
+
+
+def case_batch_sample(vocab=50, seed=41):
+    out = {}
+    B = 4
+    w = syn.decoder_weights(vocab, seed=seed)
+    f_rgb = syn.features(B, seed + 1)
+    f_dep = syn.features(B, seed + 2, scale=0.5)
+    dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    dec.load_state_dict(w)
+    dec.eval()
+    ids = dec.batch_sample(f_rgb, f_dep, syn.special_token_ids(vocab), max_length=30)
+    out["ids"] = np.asarray(ids, np.int64)
+    np.savez_compressed(os.path.join(HERE, "batch_sample.npz"), **out)
+    print("batch_sample", ids[0][:10])
+
+
+def case_depth_encoder(seed=51):
+    B = 2
+    w, st = syn.depth_encoder_weights(seed=seed)
+    depth = syn.depth_maps(B, seed=seed)
+    rg = np.random.Generator(np.random.PCG64(seed + 7))
+    d_out = torch.from_numpy(rg.standard_normal((B, 196, 2048)).astype(np.float32)) * 1e-2
+    for mode in ("train", "eval"):
+        out = {}
+        enc = Depth_CNN_endoder(14)
+        sd = dict(w)
+        sd.update(st)
+        full = enc.state_dict()
+        # state_dict has every layer twice (convN.* and features.K.*): fill both spellings
+        alias = {"conv1": "features.0", "bn1": "features.1", "conv2": "features.4", "bn2": "features.5",
+                 "conv3": "features.8", "bn3": "features.9"}
+        load = {}
+        for k in full:
+            if k.endswith("num_batches_tracked"):
+                load[k] = full[k]
+                continue
+            base = k
+            for a, b in alias.items():
+                if k.startswith(b + "."):
+                    base = a + k[len(b):]
+            load[k] = sd[base].clone()
+        enc.load_state_dict(load)
+        enc.train(mode == "train")
+        y = enc(depth)
+        pack(y.reshape(B, 14, 14, 2048)[:, ::2, ::2].reshape(B, 49, 2048), "out49", out)
+        out["replicated_ok"] = np.bool_(torch.equal(
+            y.reshape(B, 7, 2, 7, 2, 2048)[:, :, 0, :, 0], y.reshape(B, 7, 2, 7, 2, 2048)[:, :, 1, :, 1]))
+        if mode == "train":
+            (y * d_out).sum().backward()
+            for k, p in enc.named_parameters():
+                pack(p.grad, "grad." + k, out)
+            for i in (1, 2, 3):
+                pack(getattr(enc, f"bn{i}").running_mean, f"bn{i}.running_mean", out)
+                pack(getattr(enc, f"bn{i}").running_var, f"bn{i}.running_var", out)
+        np.savez_compressed(os.path.join(HERE, f"depth_encoder_{mode}.npz"), **out)
+        print("depth_encoder", mode, float(y.abs().mean()))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    case_soft_attention()
+    case_decoder("soft_ragged_eval", [9, 7, 7, 4, 3], 50, 21, train=False)
+    case_decoder("soft_ragged_train", [9, 7, 7, 4, 3], 50, 21, train=True)
+    case_decoder("soft_equal_train", [6, 6, 6, 6], 64, 22, train=True)
+    case_decoder("hard_ragged_train", [9, 7, 7, 4, 3], 50, 23, train=True, hard=True)
+    case_decoder_hard_eval("hard_ragged_evalfwd", [9, 7, 7, 4, 3], 50, 24)
+    case_adamw3()
+    case_batch_sample()
+    case_depth_encoder()
