@@ -1,0 +1,77 @@
+"""Build libdic_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+Usage: python -m depth_image_captioning_pub_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libdic_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-ffp-contract=off"]
+
+
+def _hipcc() -> str:
+    h = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(h):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return h
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "dic.h"))
+    headers = [h for h in headers if os.path.exists(h)]
+    jobs = []
+    objs = []
+    for src in _sources():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + FLAGS + ["-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
+            if src.endswith(".cpp"):
+                cmd += ["-x", "hip"]
+            cmd += ["-c", s, "-o", o]
+            jobs.append(cmd)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for " + cmd[-3])
+        return 0
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,35 @@
+// extern "C" surface of libdic_hip.so (declared in include/dic.h).
+#include "dic.h"
+#include "conv.h"
+
+using namespace dic;
+
+extern "C" {
+
+int dic_version(void) { return 100; }
+const char* dic_last_error(void) { return last_error(); }
+
+int dic_gemm_f32(int M, int N, int K, const float* A, long long lda, int a_colk, const float* B, long long ldb,
+                 int b_colk, float* C, long long ldc, const float* bias, int act, int accumulate, int splitk,
+                 float* workspace, size_t workspace_bytes, int force_tile, void* stream) {
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K;
+  p.A = a_colk ? op_colk(A, lda) : op_rowk(A, lda);
+  p.B = b_colk ? op_colk(B, ldb) : op_rowk(B, ldb);
+  p.ep = ep_store(C, ldc, bias, act);
+  p.ep.accumulate = accumulate;
+  p.splitk = splitk; p.ws = workspace;
+  DIC_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 128, "force_tile must be 0, 64 or 128");
+  if (splitk > 1)
+    DIC_REQUIRE(workspace_bytes >= gemm_splitk_ws_bytes(M, N, splitk), "dic_gemm_f32: workspace too small");
+  return gemm_launch(p, (hipStream_t)stream, force_tile);
+}
+
+int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_ohwi, const float* bias,
+                   int CO, int KH, int KW, int stride, int pad, float* y_nhwc, float* bn_partial, int* mtiles_out,
+                   int force_tile, void* stream) {
+  ConvDesc d{B, H, W, C, CO, KH, KW, stride, pad, in_nchw};
+  return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile);
+}
+
+}  // extern "C"

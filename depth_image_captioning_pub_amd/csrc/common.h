@@ -1,0 +1,87 @@
+// Shared host/device helpers for libdic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace dic {
+
+// ---- error reporting across the C ABI: never throw, return negative codes -------------------
+enum : int { DIC_OK = 0, DIC_ERR_ARG = -1, DIC_ERR_HIP = -2, DIC_ERR_WORKSPACE = -3, DIC_ERR_UNSUPPORTED = -4 };
+
+void set_last_error(const char* fmt, ...);
+const char* last_error();
+
+#define DIC_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::dic::set_last_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return ::dic::DIC_ERR_HIP;                                                         \
+    }                                                                                    \
+  } while (0)
+
+#define DIC_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::dic::set_last_error(__VA_ARGS__);     \
+      return ::dic::DIC_ERR_ARG;              \
+    }                                         \
+  } while (0)
+
+#define DIC_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != 0) return _rc;    \
+  } while (0)
+
+#define DIC_LAUNCH_CHECK() DIC_CHECK_HIP(hipGetLastError())
+
+// ---- workspace carving (caller-owned device memory, 256-B aligned slices) --------------------
+struct Carver {
+  char* base;
+  size_t off = 0;
+  size_t cap;
+  bool overflow = false;
+  Carver(void* p, size_t bytes) : base(static_cast<char*>(p)), cap(bytes) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    T* r = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    if (base != nullptr && off > cap) overflow = true;
+    return base ? r : nullptr;
+  }
+};
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over each 32-lane half
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Bijective XCD-aware block remap (guide T1): blocks b and b+8 share an XCD (speed only).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+#endif
+
+}  // namespace dic

@@ -1,0 +1,31 @@
+// Convolution (NHWC activations, OHWI weights) on the generic MFMA contraction kernel.
+#pragma once
+#include "gemm.h"
+
+namespace dic {
+
+struct ConvDesc {
+  int B, H, W, C;            // input
+  int CO, KH, KW, stride, pad;
+  int in_nchw;               // input tensor is NCHW (first layers only; uses the gather loader)
+  int OH() const { return (H + 2 * pad - KH) / stride + 1; }
+  int OW() const { return (W + 2 * pad - KW) / stride + 1; }
+  int M() const { return B * OH() * OW(); }
+  int K() const { return KH * KW * C; }
+  ConvGeom geom() const { return ConvGeom{H, W, C, OH(), OW(), KH, KW, stride, pad, in_nchw}; }
+};
+
+// y[B,OH,OW,CO] = conv(x, w) (+bias).  bn_partial (nullable): [mtiles][2][CO] column partials.
+int conv_fwd(const float* x, const ConvDesc& d, const float* w_ohwi, const float* bias, float* y,
+             float* bn_partial, int* mtiles_out, hipStream_t st, int force_tile = 0);
+int conv_mtiles(const ConvDesc& d, int force_tile = 0);
+
+// dW[CO][KH][KW][C] = sum_m dY[m,co] * patch(m)[kh,kw,c]   (split over M with workspace `ws`)
+int conv_wgrad(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk, float* ws,
+               hipStream_t st);
+// dX[B,H,W,C] for stride-1 convolutions: full correlation of dY with the flipped weights
+// w_flip[C][KH][KW][CO] (see flip_weights_kernel); pad_dgrad = KH-1-pad.
+int conv_dgrad_s1(const float* dy, const ConvDesc& d, const float* w_flip, float* dx, hipStream_t st);
+int conv_flip_weights(const float* w_ohwi, const ConvDesc& d, float* w_flip, hipStream_t st);
+
+}  // namespace dic

@@ -1,0 +1,83 @@
+// Generic exact-fp32 MFMA contraction for gfx950:  C[m,n] (+)= sum_k A(m,k) * B(n,k)
+//
+// One kernel template covers every contraction of the hot path (linear layers, implicit-GEMM
+// convolution forward / data-gradient / weight-gradient) by swapping the operand *loaders*:
+//   ROWK         A(i,k) = p[i*ld + k]              (K contiguous: activations x, weights [out][in])
+//   COLK         A(i,k) = p[k*ld + i]              (K is the slow index: "transposed" operands)
+//   IM2COL       A(m,k) = x[img, oh*s-p+kh, ow*s-p+kw, c]  NHWC, k=(kh,kw,c), C % 32 == 0
+//   GATHER       same, any C / NCHW input, scalar loads (7x7 stem convs with C_in = 1 or 3)
+//   IM2COL_COLK  B(j,k=m) = x[img(m), oh+kh.., c]  j=(kh,kw,c): weight-gradient B operand, C % 4 == 0
+//   GATHER_COLK  same, scalar (C_in = 1)
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact f32 in / f32 accumulate, 256 FLOP/clk/CU), which is
+// what the parity bar (loss within 1e-4, argmax bit-exact vs the fp32 CPU path) needs.
+// Tile: BMxBNx32, 4 waves (2x2), LDS k-major [32][BM+pad] so every fragment read is a
+// conflict-free ds_read_b32 (lanes 0-31 = 32 consecutive rows, lanes 32-63 = next k);
+// register-staged double buffering, one barrier per K tile.
+#pragma once
+#include "common.h"
+
+namespace dic {
+
+enum : int { OPK_ROWK = 0, OPK_COLK = 1, OPK_IM2COL = 2, OPK_GATHER = 3, OPK_IM2COL_COLK = 4, OPK_GATHER_COLK = 5 };
+enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+struct ConvGeom {
+  int H, W, C;      // input height / width / channels
+  int OH, OW;       // output height / width
+  int KH, KW, stride, pad;
+  int nchw;         // GATHER only: input stored NCHW instead of NHWC
+};
+
+struct GemmOperand {
+  const float* p;
+  long long ld;
+  int kind;
+  int vec;          // 16-byte vector loads are legal (alignment + ld % 4 == 0)
+  ConvGeom g;
+};
+
+struct GemmEpilogue {
+  float* C;             // output, row stride ldc
+  long long ldc;
+  const float* bias;    // per output column, or null
+  int act;
+  int accumulate;       // C += result
+  const int* row_map;   // optional: output row index = row_map[m]
+  float* stats;         // optional BN partials: [mtiles][2][N] (sum, sum of squares of the stored value)
+  float* C2;            // optional column split: columns >= nsplit go to C2[m*ldc2 + (n-nsplit)]
+  long long ldc2;
+  int nsplit;
+  float alpha;          // result scale (applied before bias)
+};
+
+struct GemmParams {
+  int M, N, K;
+  GemmOperand A, B;
+  GemmEpilogue ep;
+  int mtiles, ntiles;
+  int splitk;           // >1: raw partials go to ws[z][M][N]; splitk_reduce applies the epilogue
+  int ktiles_per_split;
+  float* ws;
+};
+
+// host side (gemm.hip)
+size_t gemm_splitk_ws_bytes(int M, int N, int splitk);
+int gemm_pick_tile(int M, int N);               // 128 or 64
+int gemm_launch(GemmParams p, hipStream_t st, int force_tile = 0);
+GemmOperand op_rowk(const float* p, long long ld);
+GemmOperand op_colk(const float* p, long long ld);
+GemmOperand op_im2col(const float* x, const ConvGeom& g);
+GemmOperand op_gather(const float* x, const ConvGeom& g);
+GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
+GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
+GemmEpilogue ep_store(float* C, long long ldc, const float* bias = nullptr, int act = ACT_NONE);
+
+// convenience: C = A(MxK, rowk) * B(NxK, rowk)^T etc. with automatic split-K for skinny shapes
+struct GemmCall {
+  GemmParams p{};
+  GemmCall(int M, int N, int K, GemmOperand A, GemmOperand B, GemmEpilogue ep) {
+    p.M = M; p.N = N; p.K = K; p.A = A; p.B = B; p.ep = ep; p.splitk = 1; p.ws = nullptr;
+  }
+};
+
+}  // namespace dic

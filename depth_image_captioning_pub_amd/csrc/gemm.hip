@@ -1,0 +1,454 @@
+// Exact-fp32 MFMA GEMM / implicit-GEMM convolution kernel for gfx950 (see gemm.h).
+#include "gemm.h"
+
+namespace dic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 32;   // K tile (floats): one 128-B line per operand row
+
+template <int KIND>
+struct KFast { static constexpr bool v = (KIND == OPK_ROWK || KIND == OPK_IM2COL || KIND == OPK_GATHER); };
+
+// ------------------------------------------------------------------------------------------
+// Operand loaders: global -> registers (NV float4 per thread) -> LDS image S[k][i] (k-major).
+//   K-fast kinds: thread -> (row = tid/8 + 32 r, k-chunk = tid%8); 8 lanes cover one 128-B line;
+//                 LDS row stride BR+1 makes the transposing ds_write_b32 conflict-free.
+//   I-fast kinds: thread -> (k = tid/(BR/4) + r*step, i4 = tid%(BR/4)); float4 along i,
+//                 ds_write_b128 rows of stride BR+4.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int BR>
+struct Loader {
+  static constexpr bool KFAST = KFast<KIND>::v;
+  static constexpr int LD = KFAST ? BR + 1 : BR + 4;
+  static constexpr int NV = BR / 32;
+  static constexpr int I4 = BR / 4;          // threads per k row (I-fast)
+  static constexpr int KSTEP = 256 / I4;     // k rows covered per pass (I-fast)
+
+  const float* p;
+  long long ld;
+  int R, K, vec;
+  ConvGeom g;
+  int kc, i4, kk0, gi;
+  bool valid[NV];
+  long long base[NV];
+  int ih0[NV], iw0[NV];
+  int jkh[4], jkw[4], jc[4];
+  bool jvalid[4];
+
+  __device__ __forceinline__ void init(const GemmOperand& op, int r0, int R_, int K_) {
+    p = op.p; ld = op.ld; R = R_; K = K_; vec = op.vec; g = op.g;
+    const int tid = threadIdx.x;
+    if constexpr (KFAST) {
+      kc = tid & 7;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const int gr = r0 + (tid >> 3) + 32 * r;
+        valid[r] = gr < R;
+        if constexpr (KIND == OPK_ROWK) {
+          base[r] = (long long)gr * ld + kc * 4;
+        } else {
+          const int ohw = g.OH * g.OW;
+          const int img = gr / ohw, rem = gr - img * ohw;
+          const int oh = rem / g.OW, ow = rem - oh * g.OW;
+          ih0[r] = oh * g.stride - g.pad;
+          iw0[r] = ow * g.stride - g.pad;
+          base[r] = (KIND == OPK_IM2COL) ? (long long)img * g.H * g.W * g.C : (long long)img;
+        }
+      }
+    } else {
+      i4 = tid % I4;
+      kk0 = tid / I4;
+      gi = r0 + i4 * 4;
+      if constexpr (KIND != OPK_COLK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gj = gi + j;
+          jvalid[j] = gj < R;
+          const int kpos = gj / g.C;
+          jc[j] = gj - kpos * g.C;
+          jkh[j] = kpos / g.KW;
+          jkw[j] = kpos - jkh[j] * g.KW;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+    if constexpr (KIND == OPK_ROWK) {
+      const int k = k0 + kc * 4;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid[r] && k < K) {
+          const float* s = p + base[r] + k0;
+          if (vec && k + 3 < K) {
+            t = *reinterpret_cast<const float4*>(s);
+          } else {
+            t.x = s[0];
+            if (k + 1 < K) t.y = s[1];
+            if (k + 2 < K) t.z = s[2];
+            if (k + 3 < K) t.w = s[3];
+          }
+        }
+        v[r] = t;
+      }
+    } else if constexpr (KIND == OPK_IM2COL) {
+      const int kpos = k0 / g.C, c0 = k0 - kpos * g.C;
+      const int kh = kpos / g.KW, kw = kpos - kh * g.KW;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ih = ih0[r] + kh, iw = iw0[r] + kw;
+        if (valid[r] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+          t = *reinterpret_cast<const float4*>(p + base[r] + ((long long)ih * g.W + iw) * g.C + c0 + kc * 4);
+        v[r] = t;
+      }
+    } else if constexpr (KIND == OPK_GATHER) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + kc * 4 + j;
+          float x = 0.f;
+          if (valid[r] && k < K) {
+            const int kpos = k / g.C, c = k - kpos * g.C;
+            const int kh = kpos / g.KW, kw = kpos - kh * g.KW;
+            const int ih = ih0[r] + kh, iw = iw0[r] + kw;
+            if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
+              const long long img = base[r];
+              const long long a = g.nchw ? ((img * g.C + c) * g.H + ih) * g.W + iw
+                                         : ((img * g.H + ih) * g.W + iw) * g.C + c;
+              x = p[a];
+            }
+          }
+          e[j] = x;
+        }
+        v[r] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    } else if constexpr (KIND == OPK_COLK) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const int k = k0 + kk0 + r * KSTEP;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && gi < R) {
+          const float* s = p + (long long)k * ld + gi;
+          if (vec && gi + 3 < R) {
+            t = *reinterpret_cast<const float4*>(s);
+          } else {
+            t.x = s[0];
+            if (gi + 1 < R) t.y = s[1];
+            if (gi + 2 < R) t.z = s[2];
+            if (gi + 3 < R) t.w = s[3];
+          }
+        }
+        v[r] = t;
+      }
+    } else {  // IM2COL_COLK / GATHER_COLK: i = (kh,kw,c) column, k = output pixel m
+      const int ohw = g.OH * g.OW;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const int m = k0 + kk0 + r * KSTEP;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < K) {
+          const int img = m / ohw, rem = m - img * ohw;
+          const int oh = rem / g.OW, ow = rem - oh * g.OW;
+          if constexpr (KIND == OPK_IM2COL_COLK) {
+            const int ih = oh * g.stride - g.pad + jkh[0], iw = ow * g.stride - g.pad + jkw[0];
+            if (jvalid[0] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
+              const float4 t = *reinterpret_cast<const float4*>(
+                  p + (((long long)img * g.H + ih) * g.W + iw) * g.C + jc[0]);
+              e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ih = oh * g.stride - g.pad + jkh[j], iw = ow * g.stride - g.pad + jkw[j];
+              if (jvalid[j] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) {
+                const long long a = g.nchw ? (((long long)img * g.C + jc[j]) * g.H + ih) * g.W + iw
+                                           : (((long long)img * g.H + ih) * g.W + iw) * g.C + jc[j];
+                e[j] = p[a];
+              }
+            }
+          }
+        }
+        v[r] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
+    const int tid = threadIdx.x;
+    if constexpr (KFAST) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const int row = (tid >> 3) + 32 * r;
+        float* d = S + (kc * 4) * LD + row;
+        d[0] = v[r].x;
+        d[LD] = v[r].y;
+        d[2 * LD] = v[r].z;
+        d[3 * LD] = v[r].w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NV; ++r)
+        *reinterpret_cast<float4*>(S + (kk0 + r * KSTEP) * LD + i4 * 4) = v[r];
+    }
+  }
+};
+
+// epilogue for one output element; returns the stored value (BN statistics use it)
+__device__ __forceinline__ float finalize_store(const GemmEpilogue& ep, int m, int n, float v) {
+  v *= ep.alpha;
+  if (ep.bias) v += ep.bias[n];
+  if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
+  else if (ep.act == ACT_SIGMOID) v = sigmoidf_(v);
+  const long long orow = ep.row_map ? ep.row_map[m] : m;
+  float* dst = (ep.C2 && n >= ep.nsplit) ? ep.C2 + orow * ep.ldc2 + (n - ep.nsplit) : ep.C + orow * ep.ldc + n;
+  if (ep.accumulate) v += *dst;
+  *dst = v;
+  return v;
+}
+
+template <int BM, int BN, int AK, int BKIND>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
+  using LA = Loader<AK, BM>;
+  using LB = Loader<BKIND, BN>;
+  constexpr int LDA = LA::LD, LDB = LB::LD;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  __shared__ __align__(16) float As[2][BK * LDA];
+  __shared__ __align__(16) float Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.mtiles * p.ntiles;
+  const int z = lb / tiles, t = lb - z * tiles;
+  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+
+  LA la;
+  LB lbld;
+  la.init(p.A, tm * BM, p.M, p.K);
+  lbld.init(p.B, tn * BN, p.N, p.K);
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int kt0 = z * p.ktiles_per_split;
+  const int kt1 = min(nk, kt0 + p.ktiles_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[LA::NV], rb[LB::NV];
+  if (kt0 < kt1) {
+    la.load(kt0 * BK, ra);
+    lbld.load(kt0 * BK, rb);
+    la.store(As[0], ra);
+    lbld.store(Bs[0], rb);
+  }
+  __syncthreads();
+
+  const int arow = wm * WM + (lane & 31);
+  const int brow = wn * WN + (lane & 31);
+  const int khalf = lane >> 5;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      la.load((kt + 1) * BK, ra);
+      lbld.load((kt + 1) * BK, rb);
+    }
+    const float* Ac = As[cur];
+    const float* Bc = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int krow = kk * 2 + khalf;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ac[krow * LDA + arow + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bc[krow * LDB + brow + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(As[cur ^ 1], ra);
+      lbld.store(Bs[cur ^ 1], rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int n0 = tn * BN + wn * WN + (lane & 31);
+  const int m0 = tm * BM + wm * WM + 4 * khalf;
+  float cs[TN], cs2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cs2[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + j * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (m < p.M && n < p.N) {
+          if (p.splitk > 1) {
+            p.ws[((long long)z * p.M + m) * p.N + n] = acc[i][j][r];
+          } else {
+            const float v = finalize_store(p.ep, m, n, acc[i][j][r]);
+            cs[j] += v;
+            cs2[j] += v * v;
+          }
+        }
+      }
+    }
+  if (p.ep.stats && p.splitk == 1) {   // per-(m-tile, column) partial sums for train-mode BatchNorm
+    float* sb = As[0];                 // safe: main loop ended on a barrier
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      cs[j] += __shfl_xor(cs[j], 32, 64);
+      cs2[j] += __shfl_xor(cs2[j], 32, 64);
+    }
+    if (wm == 0 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        sb[wn * WN + j * 32 + lane] = cs[j];
+        sb[BN + wn * WN + j * 32 + lane] = cs2[j];
+      }
+    }
+    __syncthreads();
+    if (wm == 1 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32;
+        if (n < p.N) {
+          p.ep.stats[((long long)tm * 2 + 0) * p.N + n] = cs[j] + sb[wn * WN + j * 32 + lane];
+          p.ep.stats[((long long)tm * 2 + 1) * p.N + n] = cs2[j] + sb[BN + wn * WN + j * 32 + lane];
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) {
+  const long long total = (long long)p.M * p.N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < p.splitk; ++z) s += p.ws[(long long)z * total + e];
+    const int m = (int)(e / p.N), n = (int)(e - (long long)m * p.N);
+    finalize_store(p.ep, m, n, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+GemmOperand op_rowk(const float* p, long long ld) {
+  GemmOperand o{};
+  o.p = p; o.ld = ld; o.kind = OPK_ROWK; o.vec = aligned16(p) && (ld % 4 == 0);
+  return o;
+}
+GemmOperand op_colk(const float* p, long long ld) {
+  GemmOperand o{};
+  o.p = p; o.ld = ld; o.kind = OPK_COLK; o.vec = aligned16(p) && (ld % 4 == 0);
+  return o;
+}
+GemmOperand op_im2col(const float* x, const ConvGeom& g) {
+  GemmOperand o{};
+  o.p = x; o.ld = 0; o.kind = OPK_IM2COL; o.vec = 1; o.g = g;
+  return o;
+}
+GemmOperand op_gather(const float* x, const ConvGeom& g) {
+  GemmOperand o{};
+  o.p = x; o.ld = 0; o.kind = OPK_GATHER; o.vec = 0; o.g = g;
+  return o;
+}
+GemmOperand op_im2col_colk(const float* x, const ConvGeom& g) {
+  GemmOperand o{};
+  o.p = x; o.ld = 0; o.kind = OPK_IM2COL_COLK; o.vec = 1; o.g = g;
+  return o;
+}
+GemmOperand op_gather_colk(const float* x, const ConvGeom& g) {
+  GemmOperand o{};
+  o.p = x; o.ld = 0; o.kind = OPK_GATHER_COLK; o.vec = 0; o.g = g;
+  return o;
+}
+GemmEpilogue ep_store(float* C, long long ldc, const float* bias, int act) {
+  GemmEpilogue e{};
+  e.C = C; e.ldc = ldc; e.bias = bias; e.act = act; e.alpha = 1.0f;
+  return e;
+}
+
+size_t gemm_splitk_ws_bytes(int M, int N, int splitk) {
+  return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
+}
+
+int gemm_pick_tile(int M, int N) {
+  const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, 128);
+  if (N >= 128 && t128 >= 384) return 128;
+  return 64;
+}
+
+template <int BM, int BN>
+static int launch_tile(const GemmParams& p, hipStream_t st) {
+  const dim3 grid(p.mtiles * p.ntiles * p.splitk), block(256);
+  const int a = p.A.kind, b = p.B.kind;
+#define DIC_GEMM_CASE(AK_, BK_)                                                     \
+  if (a == AK_ && b == BK_) {                                                       \
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AK_, BK_>), grid, block, 0, st, p);     \
+    return DIC_OK;                                                                  \
+  }
+  DIC_GEMM_CASE(OPK_ROWK, OPK_ROWK)
+  DIC_GEMM_CASE(OPK_ROWK, OPK_COLK)
+  DIC_GEMM_CASE(OPK_COLK, OPK_COLK)
+  DIC_GEMM_CASE(OPK_COLK, OPK_ROWK)
+  DIC_GEMM_CASE(OPK_IM2COL, OPK_ROWK)
+  DIC_GEMM_CASE(OPK_GATHER, OPK_ROWK)
+  DIC_GEMM_CASE(OPK_COLK, OPK_IM2COL_COLK)
+  DIC_GEMM_CASE(OPK_COLK, OPK_GATHER_COLK)
+#undef DIC_GEMM_CASE
+  set_last_error("gemm: unsupported operand kinds A=%d B=%d", a, b);
+  return DIC_ERR_UNSUPPORTED;
+}
+
+int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
+  DIC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape %d %d %d", p.M, p.N, p.K);
+  DIC_REQUIRE(p.A.p && p.B.p && p.ep.C, "gemm: null pointer");
+  if (p.A.kind == OPK_IM2COL) DIC_REQUIRE(p.A.g.C % 32 == 0, "im2col loader needs C %% 32 == 0 (C=%d)", p.A.g.C);
+  if (p.B.kind == OPK_IM2COL_COLK) DIC_REQUIRE(p.B.g.C % 4 == 0, "im2col_colk loader needs C %% 4 == 0");
+  const int tile = force_tile ? force_tile : gemm_pick_tile(p.M, p.N);
+  p.mtiles = ceil_div(p.M, tile);
+  p.ntiles = ceil_div(p.N, tile);
+  const int nk = ceil_div(p.K, BK);
+  if (p.splitk < 1) p.splitk = 1;
+  if (p.splitk > nk) p.splitk = nk;
+  p.ktiles_per_split = ceil_div(nk, p.splitk);
+  p.splitk = ceil_div(nk, p.ktiles_per_split);     // no empty slices
+  if (p.splitk > 1) {
+    DIC_REQUIRE(p.ws != nullptr, "gemm: split-K needs a workspace");
+    DIC_REQUIRE(p.ep.stats == nullptr, "gemm: BN statistics epilogue cannot be combined with split-K");
+  }
+  if (p.ep.alpha == 0.0f) p.ep.alpha = 1.0f;
+  int rc = (tile == 128) ? launch_tile<128, 128>(p, st) : launch_tile<64, 64>(p, st);
+  if (rc != 0) return rc;
+  DIC_LAUNCH_CHECK();
+  if (p.splitk > 1) {
+    const long long total = (long long)p.M * p.N;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    DIC_LAUNCH_CHECK();
+  }
+  return DIC_OK;
+}
+
+}  // namespace dic
