@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdic_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-ffp-contract=off"]
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
 def _hipcc() -> str:

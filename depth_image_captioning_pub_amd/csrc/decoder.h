@@ -1,0 +1,32 @@
+// Show-Attend-and-Tell decoder (soft + Gumbel "hard" attention): forward, BPTT backward, greedy decode.
+// Host orchestration + kernels live in decoder.hip; the C ABI wrappers are at the bottom of that file.
+#pragma once
+#include "dic.h"
+#include "gemm.h"
+
+namespace dic {
+
+constexpr int kL = DIC_L, kD = DIC_D, kA = DIC_A, kE = DIC_E, kH = DIC_H;
+constexpr int kG = 4 * kH;              // LSTM gate rows (i,f,g,o)
+constexpr int kXK = kE + kD + kH;       // K of the fused LSTM GEMM: [embedding | gate*ctx | h_prev]
+constexpr int kNCH = kD / 256;          // D chunks of 256 channels per workgroup (attention kernels)
+constexpr int kLCH = 4;                 // L chunks of 49 cells (score-backward kernel)
+constexpr int kS_LSTM = 9;              // split-K of the per-step LSTM gate GEMM (72 K tiles)
+constexpr int kS_DX = 4;                // split-K of the per-step dX GEMM (16 K tiles)
+
+// workspace ("tape") shared by forward and backward of one decoder call
+struct DecoderWs {
+  // forward / saved for backward
+  float *F, *P, *mean, *Wcat, *bcat, *WhT, *WbT, *Xall, *Hall, *Call, *Gact, *Qall, *ctx, *gate, *Hdrop;
+  float *slab_g, *gemm_ws;
+  // backward
+  float *dHd, *dG, *slab_dx, *dctx, *dgpre, *dq, *dalp, *pbeta, *dqp, *dwf_acc, *dbf_acc, *dPacc, *carry_dc;
+  float *dinit, *dmean, *colsum_ws;
+  int* dlen;
+  size_t gemm_ws_floats;
+  size_t bytes;
+};
+
+DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, bool* overflow);
+
+}  // namespace dic

@@ -1,0 +1,768 @@
+// Decoder of the depth-soft / depth-hard captioner on MI355X.
+//
+// Replaces CD_RNNDecoderWith{Soft,Hard}Attention.forward/eval_forward/batch_sample
+// (Captioning_models/Depth_caption_model/depth_models.py:153-305, 580-789) and
+// Soft_Attention / Hard_Attention / Gumbel_softmax (Captioning_models/attention.py:12-167),
+// plus their autograd backward (depth_train.py:219).
+//
+// Structure: time-invariant work is hoisted out of the T-step loop
+// (P = Wz F + bz, quirk Q4; embedding half of the LSTM input; vocabulary projection and every
+// weight gradient are batched over all steps as single MFMA GEMMs); per step only the
+// HBM-bound attention/context kernels and one skinny fused LSTM GEMM run.
+#include "decoder.h"
+#include <algorithm>
+#include <vector>
+
+namespace dic {
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, bool* overflow) {
+  Carver c(ws, ws_bytes);
+  DecoderWs w{};
+  const size_t BL = (size_t)B * kL, BT = (size_t)B * T;
+  w.F = c.take<float>(BL * kD);
+  w.P = c.take<float>(BL * kA);
+  w.mean = c.take<float>((size_t)B * kD);
+  w.Wcat = c.take<float>((size_t)kG * kXK);
+  w.bcat = c.take<float>(kG);
+  w.WhT = c.take<float>((size_t)kH * kA);
+  w.WbT = c.take<float>((size_t)kH * kD);
+  w.Xall = c.take<float>(BT * kXK);
+  w.Hall = c.take<float>((size_t)B * (T + 1) * kH);
+  w.Call = c.take<float>((size_t)B * (T + 1) * kH);
+  w.Gact = c.take<float>(BT * kG);
+  w.Qall = c.take<float>(BT * kA);
+  w.ctx = c.take<float>(BT * kD);
+  w.gate = c.take<float>(BT * kD);
+  w.Hdrop = c.take<float>((size_t)N * kH);
+  w.slab_g = c.take<float>((size_t)kS_LSTM * B * kG);
+  size_t g = (size_t)16 * B * 2 * kH;                       // init_linear split-K
+  g = std::max(g, (size_t)8 * N * kH);                      // dHd = dlogits * W_o   split-K 8
+  g = std::max(g, (size_t)8 * kA * kD);                     // dW_z split-K 8
+  g = std::max(g, (size_t)8 * B * kD);                      // dmean split-K
+  w.gemm_ws_floats = g;
+  w.gemm_ws = c.take<float>(g);
+  w.dHd = c.take<float>((size_t)N * kH);
+  w.dG = c.take<float>(BT * kG);
+  w.slab_dx = c.take<float>((size_t)kS_DX * B * kXK);
+  w.dctx = c.take<float>(BT * kD);
+  w.dgpre = c.take<float>(BT * kD);
+  w.dq = c.take<float>(BT * kA);
+  w.dalp = c.take<float>((size_t)kNCH * B * kL);
+  w.pbeta = c.take<float>((size_t)kNCH * B * kH);
+  w.dqp = c.take<float>((size_t)kLCH * B * kA);
+  w.dwf_acc = c.take<float>((size_t)kLCH * B * kA);
+  w.dbf_acc = c.take<float>((size_t)kLCH * B);
+  w.dPacc = c.take<float>(BL * kA);
+  w.carry_dc = c.take<float>((size_t)B * kH);
+  w.dinit = c.take<float>((size_t)B * 2 * kH);
+  w.dmean = c.take<float>((size_t)B * kD);
+  w.colsum_ws = c.take<float>((size_t)64 * std::max(std::max(V, kD), kXK));
+  w.dlen = c.take<int>((size_t)B);
+  w.bytes = c.off;
+  if (overflow) *overflow = c.overflow;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------
+// out[c*R + r] = in[r*C + c]
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < R && c < Cc) ? in[(long long)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (r < R && c < Cc) out[(long long)c * R + r] = tile[tx][j];
+  }
+}
+
+// Wcat[g][0:2176] = W_ih[g][:], Wcat[g][2176:2304] = W_hh[g][:], bcat = b_ih + b_hh
+__global__ void __launch_bounds__(256) pack_lstm_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                                         const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                         float* __restrict__ Wcat, float* __restrict__ bcat) {
+  const int g = blockIdx.x;
+  for (int k = threadIdx.x; k < kXK; k += 256)
+    Wcat[(long long)g * kXK + k] = (k < kE + kD) ? w_ih[(long long)g * (kE + kD) + k] : w_hh[g * kH + (k - kE - kD)];
+  if (threadIdx.x == 0) bcat[g] = b_ih[g] + b_hh[g];
+}
+
+// column sums of X[M][N] (row stride ld): stage 1 writes partial[RS][N]; stage 2 (RS rows) writes out[N]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, long long ld, int M, int N,
+                                                      float* __restrict__ out, int rs) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = blockIdx.y; m < M; m += rs) s += X[(long long)m * ld + n];
+  out[(long long)blockIdx.y * N + n] = s;
+}
+
+static int colsum(const float* X, long long ld, int M, int N, float* out, float* ws, hipStream_t st) {
+  const int rs = std::min(64, std::max(1, M / 8));
+  if (rs > 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), rs), dim3(256), 0, st, X, ld, M, N, ws, rs);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), 1), dim3(256), 0, st, ws, (long long)N, rs, N, out, 1);
+  } else {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), 1), dim3(256), 0, st, X, ld, M, N, out, 1);
+  }
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// F = F_rgb + F_depth ; mean[b,d] = sum_l F[b,l,d] / L          (depth_models.py:163,166)
+// grid (D/256, B), 256 threads: wave w takes l = w, w+4, ...; lanes hold float4 over 256 channels
+__global__ void __launch_bounds__(256) fuse_mean_kernel(const float* __restrict__ frgb, const float* __restrict__ fdep,
+                                                         float* __restrict__ F, float* __restrict__ mean) {
+  __shared__ float4 red[4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long base = (long long)b * kL * kD + blockIdx.x * 256 + lane * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int l = w; l < kL; l += 4) {
+    const long long o = base + (long long)l * kD;
+    float4 v = *reinterpret_cast<const float4*>(frgb + o);
+    if (fdep) {
+      const float4 u = *reinterpret_cast<const float4*>(fdep + o);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(F + o) = v;
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    float4 s = red[0][lane];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { s.x += red[i][lane].x; s.y += red[i][lane].y; s.z += red[i][lane].z; s.w += red[i][lane].w; }
+    const float inv = (float)kL;
+    s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
+    *reinterpret_cast<float4*>(mean + (long long)b * kD + blockIdx.x * 256 + lane * 4) = s;
+  }
+}
+
+// Xall[(b*T+t), 0:E] = embed[captions[b,t]]   for t < dec_len[b]        (depth_models.py:160,192)
+__global__ void __launch_bounds__(128) embed_gather_kernel(const float* __restrict__ embed,
+                                                            const long long* __restrict__ cap, int cap_stride,
+                                                            const int* __restrict__ dec_len, int T, int V,
+                                                            float* __restrict__ Xall) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  if (t >= dec_len[b]) return;
+  long long id = cap[(long long)b * cap_stride + t];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  Xall[((long long)b * T + t) * kXK + threadIdx.x] = embed[id * kE + threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------
+// forward step kernel 1: attention scores -> softmax / Gumbel -> context -> beta gate
+//   (attention.py:84-93, 12-25, 40-46; depth_models.py:185-192)
+// grid (kNCH, nb): workgroup (chunk, b) owns channels [chunk*256, +256) of batch row b.
+// The score / softmax part (P[b]: 100 KB, L2-resident) is recomputed by the 8 chunk workgroups of a
+// row; the HBM-heavy part - one pass over F[b,:,chunk] - is split between them.
+// mode 0: softmax(e); 1: softmax((e+g)/temp); 2: one-hot(argmax(e+g)), g = -log(-log(u)).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_fwd_kernel(
+    const float* __restrict__ F, const float* __restrict__ P, const float* __restrict__ Hall,
+    const float* __restrict__ WhT, const float* __restrict__ b_h, const float* __restrict__ w_full,
+    const float* __restrict__ b_full, const float* __restrict__ WbT, const float* __restrict__ b_beta,
+    int t, int T, int mode, const float* __restrict__ gumbel_u, int B, float temp,
+    float* __restrict__ alphas, float* __restrict__ Qall, float* __restrict__ ctx_all,
+    float* __restrict__ gate_all, float* __restrict__ Xall) {
+  __shared__ float h_s[kH];
+  __shared__ float q_s[2][kA];
+  __shared__ float e_s[kL + 4];
+  __shared__ float red_s[8];
+  __shared__ __align__(16) float cred[4][256];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long bt = (long long)b * T + t;
+
+  if (tid < kH) h_s[tid] = Hall[((long long)b * (T + 1) + t) * kH + tid];
+  __syncthreads();
+  {  // q = Wh h + bh   (two halves of K per output)
+    const int a = tid & (kA - 1), half = tid >> 7;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = half * 64; k < half * 64 + 64; ++k) s += WhT[k * kA + a] * h_s[k];
+    q_s[half][a] = s;
+  }
+  __syncthreads();
+  if (tid < kA) {
+    const float q = b_h[tid] + q_s[0][tid] + q_s[1][tid];
+    q_s[0][tid] = q;
+    if (chunk == 0) Qall[bt * kA + tid] = q;
+  }
+  if (chunk == 0 && tid < kH) Xall[bt * kXK + kE + kD + tid] = h_s[tid];   // h_prev slot of the LSTM input
+  __syncthreads();
+  {  // e[l] = w . relu(P[l,:] + q) + b : one 32-lane half-wave per cell, float4 per lane
+    const int l32 = lane & 31, sub = lane >> 5;
+    const float4 q4 = *reinterpret_cast<const float4*>(&q_s[0][l32 * 4]);
+    const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
+    const float bf = b_full[0];
+    const float* Pb = P + (long long)b * kL * kA;
+    for (int l = w * 2 + sub; l < kL + 7; l += 8) {
+      float s = 0.f;
+      if (l < kL) {
+        const float4 p4 = *reinterpret_cast<const float4*>(Pb + (long long)l * kA + l32 * 4);
+        s = w4.x * fmaxf(p4.x + q4.x, 0.f) + w4.y * fmaxf(p4.y + q4.y, 0.f) + w4.z * fmaxf(p4.z + q4.z, 0.f) +
+            w4.w * fmaxf(p4.w + q4.w, 0.f);
+      }
+      s = half_wave_sum(s);
+      if (l < kL && l32 == 0) e_s[l] = s + bf;
+    }
+  }
+  __syncthreads();
+  {  // attention weights over the 196 cells
+    float z = -INFINITY;
+    if (tid < kL) {
+      z = e_s[tid];
+      if (mode != 0) {
+        const float u = gumbel_u[((long long)t * B + b) * kL + tid];
+        z += -logf(-logf(u));
+        if (mode == 1) z /= temp;
+      }
+    }
+    float m = wave_max(z);
+    if (lane == 0) red_s[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+    float al;
+    if (mode == 2) {   // first index attaining the maximum -> one-hot
+      int cand = (tid < kL && z == m) ? tid : 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+      __syncthreads();
+      if (lane == 0) red_s[4 + w] = __int_as_float(cand);
+      __syncthreads();
+      const int win = min(min(__float_as_int(red_s[4]), __float_as_int(red_s[5])),
+                          min(__float_as_int(red_s[6]), __float_as_int(red_s[7])));
+      al = (tid == win) ? 1.f : 0.f;
+    } else {
+      const float ex = (tid < kL) ? expf(z - m) : 0.f;
+      const float s = wave_sum(ex);
+      if (lane == 0) red_s[4 + w] = s;
+      __syncthreads();
+      al = ex / (red_s[4] + red_s[5] + red_s[6] + red_s[7]);
+    }
+    __syncthreads();
+    if (tid < kL) {
+      e_s[tid] = al;
+      if (chunk == 0) alphas[bt * kL + tid] = al;
+    }
+  }
+  __syncthreads();
+  {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk: wave w takes l = w, w+4, ...
+    const float* Fb = F + (long long)b * kL * kD + chunk * 256 + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 7
+    for (int l = w; l < kL; l += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(Fb + (long long)l * kD);
+      const float a = e_s[l];
+      acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
+    }
+    *reinterpret_cast<float4*>(&cred[w][lane * 4]) = acc;
+  }
+  __syncthreads();
+  {  // gate = sigmoid(W_beta h + b) ; x = gate * ctx          (depth_models.py:189-190)
+    const int d = chunk * 256 + tid;
+    const float c = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
+    float s = b_beta[d];
+#pragma unroll 8
+    for (int k = 0; k < kH; ++k) s += WbT[(long long)k * kD + d] * h_s[k];
+    const float g = sigmoidf_(s);
+    ctx_all[bt * kD + d] = c;
+    gate_all[bt * kD + d] = g;
+    Xall[bt * kXK + kE + d] = g * c;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward step kernel 3: LSTM cell pointwise (reduces the split-K slabs of the gate GEMM)
+//   nn.LSTMCell gate order i,f,g,o (depth_models.py:193-194) + dropout on h for the vocabulary
+//   projection (depth_models.py:197; the carried h is NOT dropped).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kH) lstm_fwd_kernel(const float* __restrict__ slab, int nslab, int nb,
+                                                       const float* __restrict__ bcat, int t, int T,
+                                                       const float* __restrict__ drop, int packed_off,
+                                                       float* __restrict__ Hall, float* __restrict__ Call,
+                                                       float* __restrict__ Gact, float* __restrict__ Hdrop) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  float pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += slab[((long long)z * nb + b) * kG + q * kH + j];
+    pre[q] = s + bcat[q * kH + j];
+  }
+  const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+  const long long hc = ((long long)b * (T + 1) + t) * kH + j;
+  const float c = fg * Call[hc] + ig * gg;
+  const float h = og * tanhf(c);
+  Call[hc + kH] = c;
+  Hall[hc + kH] = h;
+  float* ga = Gact + ((long long)b * T + t) * kG;
+  ga[j] = ig; ga[kH + j] = fg; ga[2 * kH + j] = gg; ga[3 * kH + j] = og;
+  const float dm = drop ? drop[((long long)b * T + t) * kH + j] : 1.0f;
+  Hdrop[((long long)packed_off + b) * kH + j] = h * dm;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward step kernel 1: assemble dh_t / dc_t and LSTM pointwise backward
+//   dh_t = W_o^T dlogit_t (dropout mask applied)  +  carry from step t+1, where the carry is
+//   assembled here from step t+1's products:  dX[:,h slot] + W_h^T dq + W_beta^T dgpre.
+//   final=1: only assemble the carry into dinit (gradient of h0 | c0) after step 0.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kH) lstm_bwd_kernel(
+    int t, int T, int B, int nb_next, int have_next, int final_pass,
+    const float* __restrict__ dHd, int packed_off, const float* __restrict__ drop,
+    const float* __restrict__ slab_dx, int nslab_dx, int nb_slab, const float* __restrict__ dqp,
+    const float* __restrict__ pbeta, const float* __restrict__ W_h /*[A][H]*/,
+    const float* __restrict__ Gact, const float* __restrict__ Call, float* __restrict__ carry_dc,
+    float* __restrict__ dG, float* __restrict__ dq_all, float* __restrict__ dinit) {
+  __shared__ float dq_s[kA];
+  const int b = blockIdx.x, j = threadIdx.x;
+  float dh = 0.f, dc = 0.f;
+  const bool carry = have_next && b < nb_next;          // row b was active at step t+1
+  if (carry) {
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < kLCH; ++c) q += dqp[((long long)c * B + b) * kA + j];
+    dq_s[j] = q;
+    dq_all[((long long)b * T + (t + 1)) * kA + j] = q;
+  }
+  __syncthreads();
+  if (carry) {
+    float s = 0.f;
+    for (int z = 0; z < nslab_dx; ++z) s += slab_dx[((long long)z * nb_slab + b) * kXK + kE + kD + j];
+#pragma unroll
+    for (int c = 0; c < kNCH; ++c) s += pbeta[((long long)c * B + b) * kH + j];
+#pragma unroll 8
+    for (int a = 0; a < kA; ++a) s += dq_s[a] * W_h[a * kH + j];
+    dh = s;
+    dc = carry_dc[b * kH + j];
+  }
+  if (final_pass) {
+    dinit[b * 2 * kH + j] = dh;
+    dinit[b * 2 * kH + kH + j] = dc;
+    return;
+  }
+  const float dm = drop ? drop[((long long)b * T + t) * kH + j] : 1.0f;
+  dh += dHd[((long long)packed_off + b) * kH + j] * dm;
+  const float* ga = Gact + ((long long)b * T + t) * kG;
+  const float ig = ga[j], fg = ga[kH + j], gg = ga[2 * kH + j], og = ga[3 * kH + j];
+  const long long hc = ((long long)b * (T + 1) + t) * kH + j;
+  const float cprev = Call[hc], tc = tanhf(Call[hc + kH]);
+  const float dog = dh * tc;
+  dc += dh * og * (1.f - tc * tc);
+  carry_dc[b * kH + j] = dc * fg;
+  float* dg = dG + ((long long)b * T + t) * kG;
+  dg[j] = dc * gg * ig * (1.f - ig);
+  dg[kH + j] = dc * cprev * fg * (1.f - fg);
+  dg[2 * kH + j] = dc * ig * (1.f - gg * gg);
+  dg[3 * kH + j] = dog * og * (1.f - og);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward step kernel 3 (grid kNCH x nb): gate / context gradients for one 256-channel chunk,
+// the second pass over F[b,:,chunk] (d alpha partial), the W_beta^T dgpre partial for dh_{t-1},
+// and (chunk 0) the embedding-row scatter.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_bwd_a_kernel(
+    const float* __restrict__ F, const float* __restrict__ slab_dx, int nslab, int nb, int B, int t, int T,
+    const float* __restrict__ ctx_all, const float* __restrict__ gate_all, const float* __restrict__ W_beta,
+    const long long* __restrict__ cap, int cap_stride, int V, float* __restrict__ dctx_all,
+    float* __restrict__ dgpre_all, float* __restrict__ dalp, float* __restrict__ pbeta, float* __restrict__ dembed) {
+  __shared__ __align__(16) float dctx_s[256];
+  __shared__ float dgp_s[256];
+  __shared__ float pb_s[2][kH];
+  __shared__ float da_s[kL];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long bt = (long long)b * T + t;
+  {
+    const int d = chunk * 256 + tid;
+    float dx = 0.f;
+    for (int z = 0; z < nslab; ++z) dx += slab_dx[((long long)z * nb + b) * kXK + kE + d];
+    const float c = ctx_all[bt * kD + d], g = gate_all[bt * kD + d];
+    const float dgp = dx * c * g * (1.f - g);
+    const float dcx = dx * g;
+    dgpre_all[bt * kD + d] = dgp;
+    dctx_all[bt * kD + d] = dcx;
+    dctx_s[tid] = dcx;
+    dgp_s[tid] = dgp;
+  }
+  if (chunk == 0 && tid < kE) {   // d embed[token] += dX[:, 0:E]   (row scatter; <start> rows collide -> atomics)
+    float dx = 0.f;
+    for (int z = 0; z < nslab; ++z) dx += slab_dx[((long long)z * nb + b) * kXK + tid];
+    long long id = cap[(long long)b * cap_stride + t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    atomicAdd(dembed + id * kE + tid, dx);
+  }
+  __syncthreads();
+  {  // partial of W_beta^T dgpre over this chunk's 256 channels
+    const int k = tid & (kH - 1), half = tid >> 7;
+    float s = 0.f;
+    const float* Wb = W_beta + ((long long)chunk * 256 + half * 128) * kH + k;
+#pragma unroll 8
+    for (int d = 0; d < 128; ++d) s += dgp_s[half * 128 + d] * Wb[(long long)d * kH];
+    pb_s[half][k] = s;
+  }
+  {  // d alpha partial: dot(dctx[chunk], F[b,l,chunk]) for l = w, w+4, ...
+    const float4 dc4 = *reinterpret_cast<const float4*>(&dctx_s[lane * 4]);
+    const float* Fb = F + (long long)b * kL * kD + chunk * 256 + lane * 4;
+#pragma unroll 7
+    for (int l = w; l < kL; l += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(Fb + (long long)l * kD);
+      float s = dc4.x * v.x + dc4.y * v.y + dc4.z * v.z + dc4.w * v.w;
+      s = wave_sum(s);
+      if (lane == 0) da_s[l] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < kH) pbeta[((long long)chunk * B + b) * kH + tid] = pb_s[0][tid] + pb_s[1][tid];
+  if (tid < kL) dalp[((long long)chunk * B + b) * kL + tid] = da_s[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// backward step kernel 4 (grid kLCH x nb): softmax / Gumbel-softmax backward, score backward over a
+// 49-cell slice: dq partial, dP accumulation (P is time-invariant -> its gradient sums over steps),
+// full_att weight/bias gradient accumulators (private per (slice,row): deterministic).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_bwd_b_kernel(
+    const float* __restrict__ P, const float* __restrict__ Qall, const float* __restrict__ alphas,
+    const float* __restrict__ dalp, const float* __restrict__ dalphas_in, const float* __restrict__ w_full,
+    int B, int t, int T, const int* __restrict__ dec_len, float inv_temp, float* __restrict__ dPacc,
+    float* __restrict__ dqp, float* __restrict__ dwf_acc, float* __restrict__ dbf_acc) {
+  __shared__ float de_s[kL];
+  __shared__ float red_s[4];
+  __shared__ float dbf_s[8];
+  __shared__ __align__(16) float acc_s[8][2][kA];
+  const int lch = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long long bt = (long long)b * T + t;
+  // BPTT runs t = T-1 .. 0; row b joins at its own last step, where its accumulators are initialised
+  const bool first_step = (t == dec_len[b] - 1);
+  float al = 0.f, da = 0.f;
+  if (tid < kL) {
+    al = alphas[bt * kL + tid];
+#pragma unroll
+    for (int c = 0; c < kNCH; ++c) da += dalp[((long long)c * B + b) * kL + tid];
+    if (dalphas_in) da += dalphas_in[bt * kL + tid];
+  }
+  const float part = wave_sum(al * da);
+  if (lane == 0) red_s[w] = part;
+  __syncthreads();
+  const float dot = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+  if (tid < kL) de_s[tid] = al * (da - dot) * inv_temp;
+  __syncthreads();
+  const int l32 = lane & 31, sub = lane >> 5, hw = w * 2 + sub;      // 8 half-waves
+  const float4 q4 = *reinterpret_cast<const float4*>(Qall + bt * kA + l32 * 4);
+  const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
+  float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), dw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dbf = 0.f;
+  const int l_lo = lch * (kL / kLCH), l_hi = l_lo + kL / kLCH;
+  for (int l = l_lo + hw; l < l_hi; l += 8) {
+    const long long o = ((long long)b * kL + l) * kA + l32 * 4;
+    const float4 p4 = *reinterpret_cast<const float4*>(P + o);
+    const float de = de_s[l];
+    const float r0 = p4.x + q4.x, r1 = p4.y + q4.y, r2 = p4.z + q4.z, r3 = p4.w + q4.w;
+    float4 dp;
+    dp.x = r0 > 0.f ? de * w4.x : 0.f;
+    dp.y = r1 > 0.f ? de * w4.y : 0.f;
+    dp.z = r2 > 0.f ? de * w4.z : 0.f;
+    dp.w = r3 > 0.f ? de * w4.w : 0.f;
+    dq4.x += dp.x; dq4.y += dp.y; dq4.z += dp.z; dq4.w += dp.w;
+    dw4.x += de * fmaxf(r0, 0.f); dw4.y += de * fmaxf(r1, 0.f);
+    dw4.z += de * fmaxf(r2, 0.f); dw4.w += de * fmaxf(r3, 0.f);
+    if (l32 == 0) dbf += de;
+    float4 acc = dp;
+    if (!first_step) {
+      const float4 old = *reinterpret_cast<const float4*>(dPacc + o);
+      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    *reinterpret_cast<float4*>(dPacc + o) = acc;
+  }
+  *reinterpret_cast<float4*>(&acc_s[hw][0][l32 * 4]) = dq4;
+  *reinterpret_cast<float4*>(&acc_s[hw][1][l32 * 4]) = dw4;
+  if (l32 == 0) dbf_s[hw] = dbf;
+  __syncthreads();
+  if (tid < kA) {
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s += acc_s[i][0][tid]; s2 += acc_s[i][1][tid]; }
+    const long long o = ((long long)lch * B + b) * kA + tid;
+    dqp[o] = s;
+    dwf_acc[o] = (first_step ? 0.f : dwf_acc[o]) + s2;
+  }
+  if (tid == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += dbf_s[i];
+    const long long o = (long long)lch * B + b;
+    dbf_acc[o] = (first_step ? 0.f : dbf_acc[o]) + s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dF[b,l,d] = sum_t alpha[b,t,l] * dctx[b,t,d] + dmean[b,d] / L     (the W_z^T dP term is added by an
+// accumulating MFMA GEMM afterwards).  grid (kNCH, B); dctx of this thread's channel in registers.
+// ------------------------------------------------------------------------------------------
+template <int TMAXR>
+__global__ void __launch_bounds__(256) dF_init_kernel(const float* __restrict__ alphas, const float* __restrict__ dctx_all,
+                                                       const float* __restrict__ dmean, int T, int Tb_unused,
+                                                       const int* __restrict__ dec_len, float* __restrict__ dF) {
+  extern __shared__ __align__(16) float al_s[];   // [kL][TMAXR]
+  const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int d = chunk * 256 + tid;
+  const int Tb = min(dec_len[b], T);
+  for (int i = tid; i < kL * TMAXR; i += 256) {
+    const int l = i / TMAXR, tt = i - l * TMAXR;
+    al_s[i] = (tt < Tb) ? alphas[((long long)b * T + tt) * kL + l] : 0.f;
+  }
+  float dc[TMAXR];
+#pragma unroll
+  for (int tt = 0; tt < TMAXR; ++tt) dc[tt] = (tt < Tb) ? dctx_all[((long long)b * T + tt) * kD + d] : 0.f;
+  const float dm = dmean[(long long)b * kD + d] / (float)kL;
+  __syncthreads();
+  float* o = dF + (long long)b * kL * kD + d;
+  for (int l = 0; l < kL; ++l) {
+    float s = dm;
+#pragma unroll
+    for (int t4 = 0; t4 < TMAXR; t4 += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(&al_s[l * TMAXR + t4]);
+      s = fmaf(a.x, dc[t4], s); s = fmaf(a.y, dc[t4 + 1], s); s = fmaf(a.z, dc[t4 + 2], s); s = fmaf(a.w, dc[t4 + 3], s);
+    }
+    o[(long long)l * kD] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------
+struct StepPlan {
+  int T = 0, N = 0;
+  std::vector<int> bs, off;
+};
+
+static int make_plan(const int* dec_len, int B, StepPlan* pl) {
+  DIC_REQUIRE(B > 0 && dec_len != nullptr, "decoder: empty batch");
+  for (int b = 1; b < B; ++b)
+    DIC_REQUIRE(dec_len[b] <= dec_len[b - 1], "decoder: lengths must be sorted in descending order (util.py:95)");
+  DIC_REQUIRE(dec_len[B - 1] >= 1, "decoder: every caption needs at least one decode step");
+  pl->T = dec_len[0];
+  pl->bs.assign(pl->T, 0);
+  pl->off.assign(pl->T + 1, 0);
+  for (int t = 0; t < pl->T; ++t) {
+    int nb = 0;
+    for (int b = 0; b < B; ++b) nb += dec_len[b] > t;
+    pl->bs[t] = nb;
+    pl->off[t + 1] = pl->off[t] + nb;
+  }
+  pl->N = pl->off[pl->T];
+  return DIC_OK;
+}
+
+static int launch_transpose(const float* in, float* out, int R, int Cc, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cc, 32), ceil_div(R, 32)), dim3(256), 0, st, in, out, R, Cc);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+static int gemm(int M, int N, int K, GemmOperand A, GemmOperand B, GemmEpilogue ep, hipStream_t st, int splitk = 1,
+                float* ws = nullptr, int tile = 0) {
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K; p.A = A; p.B = B; p.ep = ep; p.splitk = splitk; p.ws = ws;
+  return gemm_launch(p, st, tile);
+}
+
+// raw split-K partial slabs [splitk][M][N] (no reduce launch; the consumer kernel sums the slabs)
+static int gemm_slabs(int M, int N, int K, GemmOperand A, GemmOperand B, float* slabs, int splitk, hipStream_t st) {
+  GemmParams p{};
+  p.M = M; p.N = N; p.K = K; p.A = A; p.B = B; p.ep = ep_store(slabs, N); p.splitk = splitk; p.ws = slabs;
+  p.raw_partials = 1;
+  return gemm_launch(p, st, 64);
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+static int check_common(const dic_decoder_weights* w, int V, int B, const void* ws) {
+  DIC_REQUIRE(w != nullptr && ws != nullptr, "decoder: null weights/workspace");
+  DIC_REQUIRE(V > 0 && B > 0, "decoder: bad sizes");
+  return DIC_OK;
+}
+
+extern "C" {
+
+size_t dic_decoder_workspace_bytes(int B, int Tmax, int V, int n_packed) {
+  bool ov;
+  return decoder_carve(nullptr, 0, B, Tmax, V, n_packed, &ov).bytes;
+}
+
+int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth,
+                    const int64_t* captions, int cap_stride, const int* dec_lengths, int B, const float* drop_mult,
+                    int mode, const float* gumbel_u, float temp, float* logits_packed, float* alphas, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_TRY(check_common(w, V, B, workspace));
+  DIC_REQUIRE(feat_rgb && captions && logits_packed && alphas, "decoder_fwd: null pointer");
+  DIC_REQUIRE(mode >= 0 && mode <= 2, "decoder_fwd: mode must be 0 (soft), 1 (gumbel-softmax) or 2 (gumbel-max)");
+  DIC_REQUIRE(mode == 0 || gumbel_u != nullptr, "decoder_fwd: hard attention needs the uniform draws");
+  StepPlan pl;
+  DIC_TRY(make_plan(dec_lengths, B, &pl));
+  const int T = pl.T, N = pl.N;
+  bool ov = false;
+  DecoderWs ws = decoder_carve(workspace, workspace_bytes, B, T, V, N, &ov);
+  DIC_REQUIRE(!ov, "decoder_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+
+  int* d_len = ws.dlen;                                  // device copy of dec_lengths
+  DIC_CHECK_HIP(hipMemcpyAsync(d_len, dec_lengths, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  DIC_CHECK_HIP(hipMemsetAsync(alphas, 0, sizeof(float) * (size_t)B * T * kL, st));
+  DIC_CHECK_HIP(hipMemsetAsync(ws.Xall, 0, sizeof(float) * (size_t)B * T * kXK, st));
+
+  // weight prep: fused LSTM weight, transposed small matrices for coalesced mat-vecs
+  hipLaunchKernelGGL(pack_lstm_kernel, dim3(kG), dim3(256), 0, st, w->w_ih, w->w_hh, w->b_ih, w->b_hh, ws.Wcat, ws.bcat);
+  DIC_TRY(launch_transpose(w->dec_att_w, ws.WhT, kA, kH, st));
+  DIC_TRY(launch_transpose(w->fbeta_w, ws.WbT, kD, kH, st));
+  // F = F_rgb + F_depth, mean over cells
+  hipLaunchKernelGGL(fuse_mean_kernel, dim3(kNCH, B), dim3(256), 0, st, feat_rgb, feat_depth, ws.F, ws.mean);
+  DIC_LAUNCH_CHECK();
+  // P = Wz F + bz  (hoisted: time-invariant, quirk Q4)
+  DIC_TRY(gemm(B * kL, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st));
+  // [h0 | c0] = init_linear(mean)  -> slot 0 of Hall / Call
+  {
+    GemmEpilogue ep = ep_store(ws.Hall, (long long)(T + 1) * kH, w->init_b);
+    ep.C2 = ws.Call; ep.ldc2 = (long long)(T + 1) * kH; ep.nsplit = kH;
+    DIC_TRY(gemm(B, 2 * kH, kD, op_rowk(ws.mean, kD), op_rowk(w->init_w, kD), ep, st, 16, ws.gemm_ws, 64));
+  }
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(T, B), dim3(kE), 0, st, w->embed, (const long long*)captions, cap_stride,
+                     d_len, T, V, ws.Xall);
+  DIC_LAUNCH_CHECK();
+
+  for (int t = 0; t < T; ++t) {
+    const int nb = pl.bs[t];
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, nb), dim3(256), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
+                       w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, temp, alphas,
+                       ws.Qall, ws.ctx, ws.gate, ws.Xall);
+    DIC_LAUNCH_CHECK();
+    DIC_TRY(gemm_slabs(nb, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
+                       ws.slab_g, kS_LSTM, st));
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(nb), dim3(kH), 0, st, ws.slab_g, kS_LSTM, nb, ws.bcat, t, T, drop_mult,
+                       pl.off[t], ws.Hall, ws.Call, ws.Gact, ws.Hdrop);
+    DIC_LAUNCH_CHECK();
+  }
+  // logits (time-major packed rows) = dropout(h) W_o^T + b_o    (depth_models.py:197,204)
+  DIC_TRY(gemm(N, V, kH, op_rowk(ws.Hdrop, kH), op_rowk(w->out_w, kH), ep_store(logits_packed, V, w->out_b), st));
+  return DIC_OK;
+}
+
+int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions, int cap_stride,
+                    const int* dec_lengths, int B, const float* drop_mult, int mode, float temp,
+                    const float* dlogits_packed, const float* dalphas, const float* alphas,
+                    const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_TRY(check_common(w, V, B, workspace));
+  DIC_REQUIRE(g && dlogits_packed && alphas && captions, "decoder_bwd: null pointer");
+  DIC_REQUIRE(mode == 0 || mode == 1, "decoder_bwd: only soft (0) and gumbel-softmax (1) attention are differentiable");
+  StepPlan pl;
+  DIC_TRY(make_plan(dec_lengths, B, &pl));
+  const int T = pl.T, N = pl.N;
+  DIC_REQUIRE(T <= 64, "decoder_bwd: at most 64 decode steps supported (got %d)", T);
+  bool ov = false;
+  DecoderWs ws = decoder_carve(workspace, workspace_bytes, B, T, V, N, &ov);
+  DIC_REQUIRE(!ov, "decoder_bwd: workspace too small");
+  const size_t BT = (size_t)B * T;
+
+  int* d_len = ws.dlen;
+  DIC_CHECK_HIP(hipMemcpyAsync(d_len, dec_lengths, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  DIC_CHECK_HIP(hipMemsetAsync(ws.dG, 0, sizeof(float) * BT * kG, st));
+  DIC_CHECK_HIP(hipMemsetAsync(ws.dgpre, 0, sizeof(float) * BT * kD, st));
+  DIC_CHECK_HIP(hipMemsetAsync(ws.dctx, 0, sizeof(float) * BT * kD, st));
+  DIC_CHECK_HIP(hipMemsetAsync(ws.dq, 0, sizeof(float) * BT * kA, st));
+  DIC_CHECK_HIP(hipMemsetAsync(g->embed, 0, sizeof(float) * (size_t)V * kE, st));
+  float* cs = ws.colsum_ws;
+
+  // vocabulary projection backward (batched over all steps)
+  DIC_TRY(gemm(N, kH, V, op_rowk(dlogits_packed, V), op_colk(w->out_w, kH), ep_store(ws.dHd, kH), st, 8, ws.gemm_ws));
+  DIC_TRY(gemm(V, kH, N, op_colk(dlogits_packed, V), op_colk(ws.Hdrop, kH), ep_store(g->out_w, kH), st));
+  DIC_TRY(colsum(dlogits_packed, V, N, V, g->out_b, cs, st));
+
+  const float inv_temp = (mode == 1) ? 1.0f / temp : 1.0f;
+  for (int t = T - 1; t >= 0; --t) {
+    const int nb = pl.bs[t];
+    const int have_next = (t + 1 < T);
+    const int nb_next = have_next ? pl.bs[t + 1] : 0;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nb), dim3(kH), 0, st, t, T, B, nb_next, have_next, 0, ws.dHd, pl.off[t],
+                       drop_mult, ws.slab_dx, kS_DX, nb_next, ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call,
+                       ws.carry_dc, ws.dG, ws.dq, ws.dinit);
+    DIC_LAUNCH_CHECK();
+    // dX = dG_t * Wcat  (K = 4H)
+    DIC_TRY(gemm_slabs(nb, kXK, kG, op_rowk(ws.dG + (long long)t * kG, (long long)T * kG), op_colk(ws.Wcat, kXK),
+                       ws.slab_dx, kS_DX, st));
+    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(kNCH, nb), dim3(256), 0, st, ws.F, ws.slab_dx, kS_DX, nb, B, t, T,
+                       ws.ctx, ws.gate, w->fbeta_w, (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre,
+                       ws.dalp, ws.pbeta, g->embed);
+    DIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3(kLCH, nb), dim3(256), 0, st, ws.P, ws.Qall, alphas, ws.dalp, dalphas,
+                       w->full_att_w, B, t, T, ws.dlen, inv_temp, ws.dPacc, ws.dqp, ws.dwf_acc, ws.dbf_acc);
+    DIC_LAUNCH_CHECK();
+  }
+  // gradient of (h0 | c0) and the dq of step 0
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(kH), 0, st, -1, T, B, pl.bs[0], 1, 1, ws.dHd, 0, drop_mult,
+                     ws.slab_dx, kS_DX, pl.bs[0], ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call, ws.carry_dc, ws.dG,
+                     ws.dq, ws.dinit);
+  DIC_LAUNCH_CHECK();
+
+  // ---- batched weight gradients ---------------------------------------------------------------
+  const float* Hprev = ws.Xall + kE + kD;                     // h_{t-1} rows, ld = kXK
+  // LSTM: [dW_ih | dW_hh] = dG^T [X | h_prev]; biases
+  {
+    GemmEpilogue ep = ep_store(g->w_ih, kE + kD);
+    ep.C2 = g->w_hh; ep.ldc2 = kH; ep.nsplit = kE + kD;
+    DIC_TRY(gemm(kG, kXK, (int)BT, op_colk(ws.dG, kG), op_colk(ws.Xall, kXK), ep, st));
+    DIC_TRY(colsum(ws.dG, kG, (int)BT, kG, g->b_ih, cs, st));
+    DIC_CHECK_HIP(hipMemcpyAsync(g->b_hh, g->b_ih, sizeof(float) * kG, hipMemcpyDeviceToDevice, st));
+  }
+  // f_beta and decoder_att
+  DIC_TRY(gemm(kD, kH, (int)BT, op_colk(ws.dgpre, kD), op_colk(Hprev, kXK), ep_store(g->fbeta_w, kH), st));
+  DIC_TRY(colsum(ws.dgpre, kD, (int)BT, kD, g->fbeta_b, cs, st));
+  DIC_TRY(gemm(kA, kH, (int)BT, op_colk(ws.dq, kA), op_colk(Hprev, kXK), ep_store(g->dec_att_w, kH), st, 8, ws.gemm_ws));
+  DIC_TRY(colsum(ws.dq, kA, (int)BT, kA, g->dec_att_b, cs, st));
+  // full_att
+  DIC_TRY(colsum(ws.dwf_acc, kA, kLCH * B, kA, g->full_att_w, cs, st));
+  DIC_TRY(colsum(ws.dbf_acc, 1, kLCH * B, 1, g->full_att_b, cs, st));
+  // encoder_att: dW_z = dP^T F, db_z = colsum(dP)
+  DIC_TRY(gemm(kA, kD, B * kL, op_colk(ws.dPacc, kA), op_colk(ws.F, kD), ep_store(g->enc_att_w, kD), st, 8, ws.gemm_ws));
+  DIC_TRY(colsum(ws.dPacc, kA, B * kL, kA, g->enc_att_b, cs, st));
+  // init_linear
+  DIC_TRY(gemm(2 * kH, kD, B, op_colk(ws.dinit, 2 * kH), op_colk(ws.mean, kD), ep_store(g->init_w, kD), st));
+  DIC_TRY(colsum(ws.dinit, 2 * kH, B, 2 * kH, g->init_b, cs, st));
+  DIC_TRY(gemm(B, kD, 2 * kH, op_rowk(ws.dinit, 2 * kH), op_colk(w->init_w, kD), ep_store(ws.dmean, kD), st, 8,
+               ws.gemm_ws, 64));
+  // ---- gradient w.r.t. the fused feature map (same for F_rgb and F_depth: F = F_rgb + F_depth) ----
+  if (d_features) {
+    if (T <= 32) {
+      hipLaunchKernelGGL((dF_init_kernel<32>), dim3(kNCH, B), dim3(256), kL * 32 * sizeof(float), st, alphas, ws.dctx,
+                         ws.dmean, T, 0, d_len, d_features);
+    } else {
+      hipLaunchKernelGGL((dF_init_kernel<64>), dim3(kNCH, B), dim3(256), kL * 64 * sizeof(float), st, alphas, ws.dctx,
+                         ws.dmean, T, 0, d_len, d_features);
+    }
+    DIC_LAUNCH_CHECK();
+    GemmEpilogue ep = ep_store(d_features, kD);
+    ep.accumulate = 1;
+    DIC_TRY(gemm(B * kL, kD, kA, op_rowk(ws.dPacc, kA), op_colk(w->enc_att_w, kD), ep, st));
+  }
+  return DIC_OK;
+}
+
+}  // extern "C"

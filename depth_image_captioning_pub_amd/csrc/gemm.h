@@ -58,6 +58,7 @@ struct GemmParams {
   int splitk;           // >1: raw partials go to ws[z][M][N]; splitk_reduce applies the epilogue
   int ktiles_per_split;
   float* ws;
+  int raw_partials;     // split-K: leave the [splitk][M][N] partial slabs in ws, skip the reduce launch
 };
 
 // host side (gemm.hip)

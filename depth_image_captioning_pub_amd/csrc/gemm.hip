@@ -442,7 +442,7 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   int rc = (tile == 128) ? launch_tile<128, 128>(p, st) : launch_tile<64, 64>(p, st);
   if (rc != 0) return rc;
   DIC_LAUNCH_CHECK();
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && !p.raw_partials) {
     const long long total = (long long)p.M * p.N;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);

@@ -1,0 +1,187 @@
+"""Thin Python functions over the C ABI (include/dic.h).  torch is used only for device memory and
+streams; every number is produced by libdic_hip.so.  Nothing here falls back to torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+L_CELLS, D_ENC, D_ATT, D_EMB, D_HID = 196, 2048, 128, 128, 128
+
+# state_dict key  ->  field of dic_decoder_weights / dic_decoder_grads (include/dic.h)
+DECODER_FIELDS = (
+    ("attention.encoder_att.weight", "enc_att_w"), ("attention.encoder_att.bias", "enc_att_b"),
+    ("attention.decoder_att.weight", "dec_att_w"), ("attention.decoder_att.bias", "dec_att_b"),
+    ("attention.full_att.weight", "full_att_w"), ("attention.full_att.bias", "full_att_b"),
+    ("embed.weight", "embed"),
+    ("decode_step.weight_ih", "w_ih"), ("decode_step.weight_hh", "w_hh"),
+    ("decode_step.bias_ih", "b_ih"), ("decode_step.bias_hh", "b_hh"),
+    ("init_linear.weight", "init_w"), ("init_linear.bias", "init_b"),
+    ("f_beta.weight", "fbeta_w"), ("f_beta.bias", "fbeta_b"),
+    ("linear.weight", "out_w"), ("linear.bias", "out_b"),
+)
+
+
+class DecoderPtrs(C.Structure):
+    """Mirrors dic_decoder_weights AND dic_decoder_grads (identical field order)."""
+    _fields_ = [(name, C.c_void_p) for name in (
+        "enc_att_w", "enc_att_b", "dec_att_w", "dec_att_b", "full_att_w", "full_att_b", "embed",
+        "w_ih", "w_hh", "b_ih", "b_hh", "init_w", "init_b", "fbeta_w", "fbeta_b", "out_w", "out_b")]
+
+
+def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.DicError(f"{what}: tensor must live on the GPU (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.DicError(f"{what}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def decoder_ptrs(tensors: Dict[str, torch.Tensor]) -> Tuple[DecoderPtrs, list]:
+    keep, s = [], DecoderPtrs()
+    for key, field in DECODER_FIELDS:
+        t = _dev_f32(tensors[key], key)
+        keep.append(t)
+        setattr(s, field, t.data_ptr())
+    return s, keep
+
+
+def _i32_host(values: Sequence[int]):
+    arr = (C.c_int * len(values))(*[int(v) for v in values])
+    return arr
+
+
+@dataclass
+class DecoderTape:
+    """Everything dic_decoder_bwd needs from the matching forward call."""
+    workspace: torch.Tensor
+    dec_len: List[int]
+    batch_sizes: List[int]
+    n_packed: int
+    tmax: int
+    vocab: int
+    captions: torch.Tensor
+    drop_mult: Optional[torch.Tensor]
+    mode: int
+    temp: float
+    alphas: torch.Tensor
+    weights: Dict[str, torch.Tensor]
+
+
+def batch_sizes_of(dec_len: Sequence[int]) -> List[int]:
+    return [sum(1 for l in dec_len if l > t) for t in range(max(dec_len))]
+
+
+def decoder_forward(weights: Dict[str, torch.Tensor], feat_rgb: torch.Tensor, feat_depth: Optional[torch.Tensor],
+                    captions: torch.Tensor, lengths: Sequence[int], drop_mult: Optional[torch.Tensor] = None,
+                    mode: int = 0, gumbel_u: Optional[torch.Tensor] = None, temp: float = 1.0,
+                    workspace: Optional[torch.Tensor] = None):
+    """dic_decoder_fwd. Returns (logits_packed [N,V], alphas [B,Tmax,196], tape)."""
+    lib = _lib.load()
+    B = feat_rgb.shape[0]
+    if tuple(feat_rgb.shape[1:]) != (L_CELLS, D_ENC):
+        raise _lib.DicError(f"features must be [B,{L_CELLS},{D_ENC}], got {tuple(feat_rgb.shape)}")
+    dec_len = [int(l) - 1 for l in lengths]
+    tmax = max(dec_len)
+    bsz = batch_sizes_of(dec_len)
+    n_packed = sum(bsz)
+    vocab = weights["linear.weight"].shape[0]
+    dev = feat_rgb.device
+    wp, keep = decoder_ptrs(weights)
+    f_rgb = _dev_f32(feat_rgb, "features")
+    f_dep = _dev_f32(feat_depth, "depth_features") if feat_depth is not None else None
+    caps = captions if captions.is_contiguous() else captions.contiguous()
+    if caps.dtype != torch.int64 or not caps.is_cuda:
+        raise _lib.DicError("captions must be an int64 GPU tensor")
+    lib.dic_decoder_workspace_bytes.restype = C.c_size_t
+    need = lib.dic_decoder_workspace_bytes(B, tmax, vocab, n_packed)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    logits = torch.empty((n_packed, vocab), dtype=torch.float32, device=dev)
+    alphas = torch.empty((B, tmax, L_CELLS), dtype=torch.float32, device=dev)
+    dm = _dev_f32(drop_mult, "drop_mult") if drop_mult is not None else None
+    gu = _dev_f32(gumbel_u, "gumbel_u") if gumbel_u is not None else None
+    rc = lib.dic_decoder_fwd(C.byref(wp), vocab, ptr(f_rgb), ptr(f_dep), ptr(caps), caps.stride(0),
+                             _i32_host(dec_len), B, ptr(dm), mode, ptr(gu), C.c_float(temp), ptr(logits), ptr(alphas),
+                             ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+    check(rc, "dic_decoder_fwd")
+    tape = DecoderTape(workspace, dec_len, bsz, n_packed, tmax, vocab, caps, dm, mode, float(temp), alphas,
+                       {k: t for (k, _), t in zip(DECODER_FIELDS, keep)})
+    return logits, alphas, tape
+
+
+def decoder_backward(tape: DecoderTape, dlogits: torch.Tensor, dalphas: Optional[torch.Tensor],
+                     grads: Optional[Dict[str, torch.Tensor]] = None, want_dfeatures: bool = True):
+    """dic_decoder_bwd. Returns (grads dict keyed like state_dict, d_features [B,196,2048] or None)."""
+    lib = _lib.load()
+    dev = dlogits.device
+    B = len(tape.dec_len)
+    if grads is None:
+        grads = {k: torch.empty_like(t) for k, t in tape.weights.items()}
+    gp, keep_g = decoder_ptrs(grads)
+    wp, keep_w = decoder_ptrs(tape.weights)
+    dfeat = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=dev) if want_dfeatures else None
+    dl = _dev_f32(dlogits, "dlogits")
+    da = _dev_f32(dalphas, "dalphas") if dalphas is not None else None
+    rc = lib.dic_decoder_bwd(C.byref(wp), tape.vocab, ptr(tape.captions), tape.captions.stride(0),
+                             _i32_host(tape.dec_len), B, ptr(tape.drop_mult), tape.mode, C.c_float(tape.temp), ptr(dl),
+                             ptr(da), ptr(tape.alphas), C.byref(gp), ptr(dfeat), ptr(tape.workspace),
+                             C.c_size_t(tape.workspace.numel()), stream_ptr())
+    check(rc, "dic_decoder_bwd")
+    return grads, dfeat
+
+
+def pack_targets(captions: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor:
+    lib = _lib.load()
+    dec_len = [int(l) - 1 for l in lengths]
+    n = sum(batch_sizes_of(dec_len))
+    buf = torch.empty(n + max(dec_len) + 2, dtype=torch.int64, device=captions.device)
+    caps = captions if captions.is_contiguous() else captions.contiguous()
+    check(lib.dic_pack_targets(ptr(caps), caps.stride(0), _i32_host(dec_len), len(dec_len), ptr(buf), stream_ptr()),
+          "dic_pack_targets")
+    return buf[:n]
+
+
+def caption_loss(logits: torch.Tensor, targets: torch.Tensor, alphas: Optional[torch.Tensor], lam: float = 0.7,
+                 grad_scale: float = 1.0, in_place: bool = False):
+    """dic_caption_loss. Returns (loss [1] device tensor, dlogits, dalphas or None)."""
+    lib = _lib.load()
+    n, v = logits.shape
+    dev = logits.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dlogits = logits if in_place else torch.empty_like(logits)
+    B = alphas.shape[0] if alphas is not None else 0
+    T = alphas.shape[1] if alphas is not None else 0
+    dalphas = torch.empty_like(alphas) if alphas is not None else None
+    scratch = torch.empty(n + B + 8, dtype=torch.float32, device=dev)
+    rc = lib.dic_caption_loss(ptr(logits), ptr(targets), n, v, ptr(alphas), B, T, C.c_float(lam), C.c_float(grad_scale),
+                              ptr(loss), ptr(dlogits), ptr(dalphas), ptr(scratch), stream_ptr())
+    check(rc, "dic_caption_loss")
+    return loss, dlogits, dalphas
+
+
+def adamw_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+               lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+               weight_decay: float = 0.01) -> None:
+    lib = _lib.load()
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise _lib.DicError("adamw_step needs contiguous fp32 GPU buffers")
+    rc = lib.dic_adamw_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), C.c_longlong(params.numel()), step,
+                            C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
+                            stream_ptr())
+    check(rc, "dic_adamw_step")
+
+
+def dropout_mask(shape, p: float, seed: int, offset: int, device) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    rc = lib.dic_dropout_mask(ptr(out), C.c_longlong(out.numel()), C.c_float(p), C.c_uint64(seed), C.c_uint64(offset),
+                              stream_ptr())
+    check(rc, "dic_dropout_mask")
+    return out

@@ -48,6 +48,73 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
                    int CO, int KH, int KW, int stride, int pad, float* y_nhwc, float* bn_partial, int* mtiles_out,
                    int force_tile, void* stream);
 
+
+/* ---- decoder: CD_RNNDecoderWith{Soft,Hard}Attention (Depth_caption_model/depth_models.py:96-305,
+ *      522-789) incl. Soft_Attention / Hard_Attention / Gumbel_softmax (attention.py:6-167).
+ *      Pointers follow the reference's state_dict names and native layouts ([out][in] row-major). */
+typedef struct dic_decoder_weights {
+  const float *enc_att_w, *enc_att_b;     /* attention.encoder_att  [A,D],[A]   (attention.py:64)  */
+  const float *dec_att_w, *dec_att_b;     /* attention.decoder_att  [A,H],[A]   (attention.py:67)  */
+  const float *full_att_w, *full_att_b;   /* attention.full_att     [1,A],[1]   (attention.py:70)  */
+  const float *embed;                     /* embed.weight           [V,E]       (depth_models.py:118) */
+  const float *w_ih, *w_hh, *b_ih, *b_hh; /* decode_step            [4H,E+D],[4H,H],[4H],[4H] (:122) */
+  const float *init_w, *init_b;           /* init_linear            [2H,D],[2H] (:126) */
+  const float *fbeta_w, *fbeta_b;         /* f_beta                 [D,H],[D]   (:129) */
+  const float *out_w, *out_b;             /* linear                 [V,H],[V]   (:132) */
+} dic_decoder_weights;
+
+typedef struct dic_decoder_grads {        /* same order, written (not accumulated) by dic_decoder_bwd */
+  float *enc_att_w, *enc_att_b, *dec_att_w, *dec_att_b, *full_att_w, *full_att_b, *embed;
+  float *w_ih, *w_hh, *b_ih, *b_hh, *init_w, *init_b, *fbeta_w, *fbeta_b, *out_w, *out_b;
+} dic_decoder_grads;
+
+/* bytes of device scratch ("tape") one forward+backward pair needs; n_packed = sum(dec_lengths) */
+size_t dic_decoder_workspace_bytes(int B, int Tmax, int V, int n_packed);
+
+/* forward (depth_models.py:153-207 soft, 580-634 hard-train, 637-689 hard-eval).
+ *   feat_rgb/feat_depth: [B,196,2048] contiguous (feat_depth may be NULL = base-* models);
+ *   captions: int64 [B,cap_stride] on device; dec_lengths: HOST int[B] = lengths-1, descending;
+ *   drop_mult: [B,Tmax,H] multiplier (0 or 1/(1-p)) or NULL for eval (quirk Q6: mask is an input);
+ *   mode 0 soft | 1 Gumbel-softmax with temp (attention.py:12-25) | 2 Gumbel-max one-hot (:34-48);
+ *   gumbel_u: [Tmax,B,196] uniform draws (modes 1,2);
+ *   logits_packed: [n_packed,V] time-major rows (= PackedSequence.data, :204); alphas: [B,Tmax,196]. */
+int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth,
+                    const int64_t* captions, int cap_stride, const int* dec_lengths, int B, const float* drop_mult,
+                    int mode, const float* gumbel_u, float temp, float* logits_packed, float* alphas, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* backward of the call above (autograd of depth_train.py:219 restricted to the decoder): consumes the
+ * workspace left by dic_decoder_fwd.  dalphas may be NULL.  d_features [B,196,2048] (nullable) is the
+ * gradient w.r.t. BOTH feat_rgb and feat_depth (they are summed, depth_models.py:163). */
+int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions, int cap_stride,
+                    const int* dec_lengths, int B, const float* drop_mult, int mode, float temp,
+                    const float* dlogits_packed, const float* dalphas, const float* alphas,
+                    const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* ---- loss of train_Cdepth_soft (depth_train.py:210-216): mean CE over packed tokens
+ *      + lam * mean_{B,L}((1 - sum_t alpha)^2).  targets: int64 [n_packed] (device, packed like the
+ *      logits).  Writes loss[0] (device), dlogits [n_packed,V] (may alias logits) and, if alphas is
+ *      non-NULL, dalphas [B,Tmax,196].  alphas NULL -> CE only (hard path, depth_train.py:530).
+ *      grad_scale multiplies both gradients (1/world_size for data parallel).
+ *      scratch: >= (n_packed + B + 8) floats. */
+int dic_caption_loss(const float* logits, const int64_t* targets, int n_packed, int V, const float* alphas, int B,
+                     int Tmax, float lam, float grad_scale, float* loss, float* dlogits, float* dalphas,
+                     float* scratch, void* stream);
+/* packed targets = pack_padded_sequence(captions[:,1:], lengths-1).data (depth_train.py:210-213);
+ * `targets` needs room for n_packed + Tmax int64 (the tail stages two small int tables). */
+int dic_pack_targets(const int64_t* captions, int cap_stride, const int* dec_lengths, int B, int64_t* targets,
+                     void* stream);
+
+/* ---- optimiser: torch.optim.AdamW defaults on a flat fp32 buffer (depth_train.py:136-137,221);
+ *      `step` is the 1-based step number. */
+int dic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* ---- dropout multiplier (nn.Dropout(p) in train mode, depth_models.py:119,197): out[i] = 0 or 1/(1-p),
+ *      Philox4x32-10 counter-based stream keyed by (seed, offset). */
+int dic_dropout_mask(float* out, long long n, float p, uint64_t seed, uint64_t offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
