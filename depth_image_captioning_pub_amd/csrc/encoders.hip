@@ -1,0 +1,308 @@
+// The two CNN encoders of the depth-soft captioner on MI355X (NHWC activations, exact-fp32 MFMA
+// implicit-GEMM convolutions, train-mode BatchNorm statistics from the conv epilogue).
+//
+//   depth encoder : Depth_CNN_endoder (Depth_caption_model/depth_models.py:12-56), forward + backward
+//   RGB encoder   : CNNEncoder_Atten = torchvision ResNet-152 children()[:-1] with
+//                   AdaptiveAvgPool2d(14) (Base_caption_model/base_caption_models.py:18-45), forward
+//                   only (@torch.no_grad), BatchNorm in batch-statistics mode when train_bn (quirk Q1).
+#include "dic.h"
+#include "conv.h"
+#include "nn_kernels.h"
+#include <algorithm>
+#include <vector>
+
+namespace dic {
+
+// ------------------------------------------------------------------------------------------
+// depth encoder
+// ------------------------------------------------------------------------------------------
+struct DepthGeom {
+  int B, H, W;
+  int H1, W1, P1h, P1w, H2, W2, P2h, P2w;
+  ConvDesc c1, c2, c3;
+  long long M1, M2, M3;
+};
+
+static DepthGeom depth_geom(int B, int H, int W) {
+  DepthGeom g{};
+  g.B = B; g.H = H; g.W = W;
+  g.c1 = ConvDesc{B, H, W, 1, 128, 7, 7, 3, 0, 1};
+  g.H1 = g.c1.OH(); g.W1 = g.c1.OW();
+  g.P1h = g.H1 / 3; g.P1w = g.W1 / 3;
+  g.c2 = ConvDesc{B, g.P1h, g.P1w, 128, 512, 3, 3, 1, 0, 0};
+  g.H2 = g.c2.OH(); g.W2 = g.c2.OW();
+  g.P2h = g.H2 / 3; g.P2w = g.W2 / 3;
+  g.c3 = ConvDesc{B, g.P2h, g.P2w, 512, 2048, 1, 1, 1, 0, 0};
+  g.M1 = (long long)B * g.H1 * g.W1; g.M2 = (long long)B * g.H2 * g.W2; g.M3 = (long long)B * g.P2h * g.P2w;
+  return g;
+}
+
+constexpr int kWg1Split = 128;   // split-K of the conv1 weight gradient (K = B*73*73)
+constexpr int kWg2Split = 4;
+
+struct DepthWs {
+  float *w2o, *x1, *y1p, *x2, *y2p, *x3, *partial;
+  unsigned char *idx1, *idx2;
+  BnBuf bn1, bn2, bn3;
+  // backward
+  float *dy1, *dy1p, *dy2, *dy2p, *dy3, *w2f, *w3f, *dw2o, *wg_ws, *bn_ws, *cs_ws;
+  size_t bytes;
+};
+
+static BnBuf take_bn(Carver& c, int C) {
+  BnBuf b;
+  b.scale = c.take<float>(C); b.shift = c.take<float>(C); b.mean = c.take<float>(C); b.invstd = c.take<float>(C);
+  return b;
+}
+
+static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) {
+  Carver c(p, bytes);
+  DepthWs w{};
+  const long long B = g.B;
+  w.w2o = c.take<float>((size_t)512 * 1152);
+  w.x1 = c.take<float>((size_t)g.M1 * 128);
+  w.y1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
+  w.idx1 = c.take<unsigned char>((size_t)B * g.P1h * g.P1w * 128);
+  w.x2 = c.take<float>((size_t)g.M2 * 512);
+  w.y2p = c.take<float>((size_t)B * g.P2h * g.P2w * 512);
+  w.idx2 = c.take<unsigned char>((size_t)B * g.P2h * g.P2w * 512);
+  w.x3 = c.take<float>((size_t)g.M3 * 2048);
+  size_t part = (size_t)(g.M1 / 64 + 2) * 2 * 128;
+  part = std::max(part, (size_t)(g.M2 / 64 + 2) * 2 * 512);
+  part = std::max(part, (size_t)(g.M3 / 64 + 2) * 2 * 2048);
+  w.partial = c.take<float>(part);
+  w.bn1 = take_bn(c, 128); w.bn2 = take_bn(c, 512); w.bn3 = take_bn(c, 2048);
+  w.dy1 = c.take<float>((size_t)g.M1 * 128);
+  w.dy1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
+  w.dy2 = c.take<float>((size_t)g.M2 * 512);
+  w.dy2p = c.take<float>((size_t)B * g.P2h * g.P2w * 512);
+  w.dy3 = c.take<float>((size_t)g.M3 * 2048);
+  w.w2f = c.take<float>((size_t)512 * 1152);
+  w.w3f = c.take<float>((size_t)512 * 2048);
+  w.dw2o = c.take<float>((size_t)512 * 1152);
+  w.wg_ws = c.take<float>(std::max((size_t)kWg1Split * 128 * 49, (size_t)kWg2Split * 512 * 1152));
+  w.bn_ws = c.take<float>(bn_backward_ws_floats(2048));
+  w.cs_ws = c.take<float>((size_t)256 * 2048);
+  w.bytes = c.off;
+  if (ov) *ov = c.overflow;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// ResNet (Bottleneck v1.5) plan
+// ------------------------------------------------------------------------------------------
+struct RnConv {
+  ConvDesc d;
+  int layer;     // index into the dic_conv_bn_layer array
+};
+
+struct RnPlan {
+  std::vector<RnConv> convs;       // execution order == layer order
+  size_t max_act = 0, max_partial = 0;
+  int outH = 0, outW = 0;
+};
+
+static void rn_track(RnPlan& pl, const ConvDesc& d) {
+  pl.max_act = std::max(pl.max_act, (size_t)d.M() * d.CO);
+  pl.max_partial = std::max(pl.max_partial, (size_t)(d.M() / 64 + 2) * 2 * d.CO);
+}
+
+static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
+  RnPlan pl;
+  int li = 0;
+  ConvDesc stem{B, H, W, 3, 64, 7, 7, 2, 3, 1};
+  pl.convs.push_back({stem, li++});
+  rn_track(pl, stem);
+  int h = stem.OH(), w = stem.OW();
+  h = (h + 2 - 3) / 2 + 1; w = (w + 2 - 3) / 2 + 1;      // maxpool 3x3 s2 p1
+  int inpl = 64;
+  const int planes_of[4] = {64, 128, 256, 512};
+  for (int s = 0; s < 4; ++s) {
+    const int planes = planes_of[s];
+    for (int b = 0; b < blocks[s]; ++b) {
+      const int stride = (s > 0 && b == 0) ? 2 : 1;
+      ConvDesc c1{B, h, w, inpl, planes, 1, 1, 1, 0, 0};
+      ConvDesc c2{B, h, w, planes, planes, 3, 3, stride, 1, 0};
+      const int oh = c2.OH(), ow = c2.OW();
+      ConvDesc c3{B, oh, ow, planes, planes * 4, 1, 1, 1, 0, 0};
+      pl.convs.push_back({c1, li++}); rn_track(pl, c1);
+      pl.convs.push_back({c2, li++}); rn_track(pl, c2);
+      pl.convs.push_back({c3, li++}); rn_track(pl, c3);
+      if (b == 0) {
+        ConvDesc ds{B, h, w, inpl, planes * 4, 1, 1, stride, 0, 0};
+        pl.convs.push_back({ds, li++}); rn_track(pl, ds);
+      }
+      h = oh; w = ow; inpl = planes * 4;
+    }
+  }
+  pl.outH = h; pl.outW = w;
+  return pl;
+}
+
+struct RnWs {
+  float* act[4];
+  float* partial;
+  BnBuf bn;
+  size_t bytes;
+};
+
+static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, bool* ov) {
+  Carver c(p, bytes);
+  RnWs w{};
+  for (int i = 0; i < 4; ++i) w.act[i] = c.take<float>(pl.max_act);
+  w.partial = c.take<float>(pl.max_partial);
+  w.bn = take_bn(c, 2048);
+  w.bytes = c.off;
+  if (ov) *ov = c.overflow;
+  return w;
+}
+
+// conv -> (train: batch statistics from the epilogue partials | eval: running stats) -> scale/shift in bn
+static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L, float* y, float* partial, BnBuf bn,
+                   int train_bn, hipStream_t st) {
+  int mtiles = 0;
+  DIC_TRY(conv_fwd(x, d, L.w, nullptr, y, train_bn ? partial : nullptr, &mtiles, st));
+  if (train_bn)
+    return bn_finalize_train(partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream) {
+  DIC_REQUIRE(src && dst && src != dst, "oihw_to_ohwi: bad pointers");
+  return oihw_to_ohwi(src, dst, O, I, KH, KW, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t dic_depth_encoder_workspace_bytes(int B, int H, int W) {
+  bool ov;
+  return depth_carve(nullptr, 0, depth_geom(B, H, W), &ov).bytes;
+}
+
+int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
+                          int H, int W, int train, float* features, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(w && s && depth && features && workspace, "depth_encoder_fwd: null pointer");
+  DIC_REQUIRE(B > 0 && H >= 43 && W >= 43, "depth_encoder_fwd: input too small (%dx%d)", H, W);
+  const DepthGeom g = depth_geom(B, H, W);
+  DIC_REQUIRE(g.P2h >= 1 && g.P2w >= 1, "depth_encoder_fwd: input too small");
+  bool ov = false;
+  DepthWs ws = depth_carve(workspace, workspace_bytes, g, &ov);
+  DIC_REQUIRE(!ov, "depth_encoder_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+  int mt = 0;
+  DIC_TRY(oihw_to_ohwi(w->conv2_w, ws.w2o, 512, 128, 3, 3, st));
+  // conv1 (1->128, k7 s3) + BN + ReLU + maxpool3          (depth_models.py:19-20,36-39)
+  DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
+  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
+  else DIC_TRY(bn_finalize_eval(128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
+  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st));
+  // conv2 (128->512, k3) + BN + ReLU + maxpool3            (:21-22,40-43)
+  DIC_TRY(conv_fwd(ws.y1p, g.c2, ws.w2o, w->conv2_b, ws.x2, train ? ws.partial : nullptr, &mt, st));
+  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M2, 512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
+  else DIC_TRY(bn_finalize_eval(512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
+  DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st));
+  // conv3 (512->2048, k1) + BN + ReLU + AdaptiveAvgPool(14) -> [B,196,2048]   (:23-24,44-47,54)
+  DIC_TRY(conv_fwd(ws.y2p, g.c3, w->conv3_w, w->conv3_b, ws.x3, train ? ws.partial : nullptr, &mt, st));
+  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
+  else DIC_TRY(bn_finalize_eval(2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
+  DIC_TRY(adaptive_avgpool(ws.x3, B, g.P2h, g.P2w, 2048, &ws.bn3, 1, 14, features, st));
+  return DIC_OK;
+}
+
+int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth, const float* d_features, int B, int H,
+                          int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(w && depth && d_features && gr && workspace, "depth_encoder_bwd: null pointer");
+  const DepthGeom g = depth_geom(B, H, W);
+  bool ov = false;
+  DepthWs ws = depth_carve(workspace, workspace_bytes, g, &ov);
+  DIC_REQUIRE(!ov, "depth_encoder_bwd: workspace too small");
+  // layer 3
+  DIC_TRY(adaptive_avgpool_bwd(d_features, B, g.P2h, g.P2w, 2048, 14, ws.dy3, st));
+  DIC_TRY(relu_mask_bwd(ws.dy3, ws.x3, g.M3, 2048, ws.bn3, st));
+  DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st));
+  DIC_TRY(conv_wgrad(ws.y2p, g.c3, ws.dy3, gr->conv3_w, 1, nullptr, st));        // OHWI == OIHW for 1x1
+  DIC_TRY(colsum_rows(ws.dy3, 2048, g.M3, 2048, gr->conv3_b, ws.cs_ws, st));
+  DIC_TRY(conv_flip_weights(w->conv3_w, g.c3, ws.w3f, st));
+  DIC_TRY(conv_dgrad_s1(ws.dy3, g.c3, ws.w3f, ws.dy2p, st));
+  // layer 2
+  DIC_TRY(maxpool_relu_bwd(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, ws.bn2, ws.dy2, st));
+  DIC_TRY(bn_backward(ws.dy2, ws.x2, g.M2, 512, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b, ws.bn_ws, st));
+  DIC_TRY(conv_wgrad(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2Split, ws.wg_ws, st));
+  DIC_TRY(ohwi_to_oihw(ws.dw2o, gr->conv2_w, 512, 128, 3, 3, st));
+  DIC_TRY(colsum_rows(ws.dy2, 512, g.M2, 512, gr->conv2_b, ws.cs_ws, st));
+  DIC_TRY(conv_flip_weights(ws.w2o, g.c2, ws.w2f, st));
+  DIC_TRY(conv_dgrad_s1(ws.dy2, g.c2, ws.w2f, ws.dy1p, st));
+  // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
+  DIC_TRY(maxpool_relu_bwd(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, ws.bn1, ws.dy1, st));
+  DIC_TRY(bn_backward(ws.dy1, ws.x1, g.M1, 128, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b, ws.bn_ws, st));
+  DIC_TRY(conv_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, kWg1Split, ws.wg_ws, st)); // C_in = 1: OHWI == OIHW
+  DIC_TRY(colsum_rows(ws.dy1, 128, g.M1, 128, gr->conv1_b, ws.cs_ws, st));
+  return DIC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int dic_resnet_num_layers(const int* blocks) {
+  int n = 1;
+  for (int s = 0; s < 4; ++s) n += 3 * blocks[s] + 1;
+  return n;
+}
+
+size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks) {
+  bool ov;
+  return rn_carve(nullptr, 0, resnet_plan(B, H, W, blocks), &ov).bytes;
+}
+
+int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
+                   int H, int W, int train_bn, float* features, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(layers && blocks && imgs_nchw && features && workspace, "resnet_fwd: null pointer");
+  DIC_REQUIRE(n_layers == dic_resnet_num_layers(blocks), "resnet_fwd: expected %d conv+bn layers, got %d",
+              dic_resnet_num_layers(blocks), n_layers);
+  DIC_REQUIRE(B > 0 && H >= 32 && W >= 32, "resnet_fwd: bad input size");
+  const RnPlan pl = resnet_plan(B, H, W, blocks);
+  bool ov = false;
+  RnWs ws = rn_carve(workspace, workspace_bytes, pl, &ov);
+  DIC_REQUIRE(!ov, "resnet_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+
+  size_t ci = 0;
+  float *X = ws.act[0], *A = ws.act[1], *Bf = ws.act[2], *Cf = ws.act[3];
+  // stem: conv7x7 s2 + BN + ReLU + maxpool 3x3 s2 p1
+  {
+    const RnConv& c = pl.convs[ci++];
+    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, train_bn, st));
+    DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
+  }
+  for (int s = 0; s < 4; ++s)
+    for (int b = 0; b < blocks[s]; ++b) {
+      const RnConv& c1 = pl.convs[ci++];
+      const RnConv& c2 = pl.convs[ci++];
+      const RnConv& c3 = pl.convs[ci++];
+      DIC_TRY(conv_bn(X, c1.d, layers[c1.layer], A, ws.partial, ws.bn, train_bn, st));
+      DIC_TRY(bn_apply(A, nullptr, A, c1.d.M(), c1.d.CO, ws.bn, 1, st));
+      DIC_TRY(conv_bn(A, c2.d, layers[c2.layer], Bf, ws.partial, ws.bn, train_bn, st));
+      DIC_TRY(bn_apply(Bf, nullptr, Bf, c2.d.M(), c2.d.CO, ws.bn, 1, st));
+      const float* identity = X;
+      if (b == 0) {
+        const RnConv& ds = pl.convs[ci++];
+        DIC_TRY(conv_bn(X, ds.d, layers[ds.layer], Cf, ws.partial, ws.bn, train_bn, st));
+        DIC_TRY(bn_apply(Cf, nullptr, Cf, ds.d.M(), ds.d.CO, ws.bn, 0, st));
+        identity = Cf;
+      }
+      DIC_TRY(conv_bn(Bf, c3.d, layers[c3.layer], A, ws.partial, ws.bn, train_bn, st));
+      DIC_TRY(bn_apply(A, identity, Bf, c3.d.M(), c3.d.CO, ws.bn, 1, st));      // out = relu(bn3 + identity)
+      std::swap(X, Bf);
+    }
+  // AdaptiveAvgPool2d(14) + permute(0,2,3,1).flatten(1,2): NHWC already is [B,196,2048]
+  DIC_TRY(adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, 14, features, st));
+  return DIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// BatchNorm / pooling / elementwise kernels shared by the two CNN encoders (NHWC activations).
+#pragma once
+#include "common.h"
+
+namespace dic {
+
+constexpr float kBnEps = 1e-5f;      // nn.BatchNorm2d defaults
+constexpr float kBnMomentum = 0.1f;
+
+// per-layer BatchNorm scratch: scale/shift used by the apply kernels, mean/invstd saved for backward
+struct BnBuf {
+  float *scale, *shift, *mean, *invstd;
+};
+
+// train mode: reduce the conv epilogue's per-tile partial sums [mtiles][2][C] (fp64), produce
+// scale/shift (+ saved mean/invstd) and update the running statistics (unbiased variance).
+int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, BnBuf out, hipStream_t st);
+// eval mode: scale/shift from the running statistics
+int bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, BnBuf out, hipStream_t st);
+// y = act(x*scale[c] + shift[c] (+ residual)); y may alias x. n = rows*C, C % 4 == 0.
+int bn_apply(const float* x, const float* residual, float* y, long long rows, int C, BnBuf bn, int relu,
+             hipStream_t st);
+// y[b,ph,pw,c] = max over kxk window (stride s, pad p) of act(x*scale+shift); idx (nullable) = kh*k+kw of the max
+int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
+                    float* y, unsigned char* idx, hipStream_t st);
+// adaptive average pooling of an NHWC map to OUTxOUT (AdaptiveAvgPool2d(14): exact 2x2 replication for 7x7)
+// with optional fused BN+ReLU on load
+int adaptive_avgpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int out, float* y,
+                     hipStream_t st);
+int adaptive_avgpool_bwd(const float* dy, int B, int H, int W, int C, int out, float* dx, hipStream_t st);
+
+// backward helpers (depth encoder)
+// dy[b,h,w,c] = (argmax of window == this pixel ? dpool : 0) * (x*scale+shift > 0)   (k == stride, no padding)
+int maxpool_relu_bwd(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C,
+                     int k, BnBuf bn, float* dy, hipStream_t st);
+// dy *= (x*scale+shift > 0)
+int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hipStream_t st);
+// BatchNorm backward (train mode): dgamma, dbeta and dx (in place over dy). ws: >= 2*64*C + 3*C floats.
+int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
+                float* dbeta, float* ws, hipStream_t st);
+size_t bn_backward_ws_floats(int C);
+// column sums (bias gradients): out[c] = sum_r X[r*ld + c]
+int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st);
+// layout transforms for weights: OIHW <-> OHWI
+int oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, hipStream_t st);
+int ohwi_to_oihw(const float* src, float* dst, int O, int I, int KH, int KW, hipStream_t st);
+
+}  // namespace dic

@@ -1,0 +1,463 @@
+// BatchNorm / pooling / elementwise kernels of the CNN encoders (NHWC, fp32). All HBM-bound:
+// 16-byte vector accesses, channel index on the fastest-varying lanes, grid-stride loops.
+#include "nn_kernels.h"
+#include <algorithm>
+
+namespace dic {
+
+static inline int ew_blocks(long long n_items) { return (int)std::min<long long>((n_items + 255) / 256, 8192); }
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm statistics -> scale/shift
+// ------------------------------------------------------------------------------------------
+// 256 threads = 32 channels x 8 tile-lanes; fp64 accumulation across the conv epilogue's tile partials
+__global__ void __launch_bounds__(256) bn_finalize_train_kernel(const float* __restrict__ partial, int mtiles,
+                                                                 double count, int C, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                 BnBuf out) {
+  __shared__ double s1[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int t = g; t < mtiles; t += 8) {
+      a += (double)partial[((long long)t * 2 + 0) * C + c];
+      b += (double)partial[((long long)t * 2 + 1) * C + c];
+    }
+  s1[g][cl] = a; s2[g][cl] = b;
+  __syncthreads();
+  if (g == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { a += s1[i][cl]; b += s2[i][cl]; }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = 1.0f / sqrtf((float)var + kBnEps);
+    const float sc = gamma[c] * invstd;
+    out.scale[c] = sc;
+    out.shift[c] = beta[c] - (float)mean * sc;
+    out.mean[c] = (float)mean;
+    out.invstd[c] = invstd;
+    if (rmean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
+      rvar[c] = (1.f - kBnMomentum) * rvar[c] + kBnMomentum * (float)unb;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_eval_kernel(int C, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ rmean,
+                                                                const float* __restrict__ rvar, BnBuf out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rvar[c] + kBnEps);
+  const float sc = gamma[c] * invstd;
+  out.scale[c] = sc;
+  out.shift[c] = beta[c] - rmean[c] * sc;
+  out.mean[c] = rmean[c];
+  out.invstd[c] = invstd;
+}
+
+int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, BnBuf out, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, partial, mtiles, (double)count,
+                     C, gamma, beta, running_mean, running_var, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     BnBuf out, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, gamma, beta, running_mean,
+                     running_var, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// y = act(x*scale + shift (+ residual))
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        float* __restrict__ y, long long n4, int C4, BnBuf bn, int relu) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 s = *reinterpret_cast<const float4*>(bn.scale + c);
+    const float4 t = *reinterpret_cast<const float4*>(bn.shift + c);
+    v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+int bn_apply(const float* x, const float* residual, float* y, long long rows, int C, BnBuf bn, int relu,
+             hipStream_t st) {
+  DIC_REQUIRE(C % 4 == 0, "bn_apply: C %% 4");
+  const long long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, y, n4, C / 4, bn, relu);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused BN + ReLU + max pooling (records the argmax position for the backward pass)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
+                                                               BnBuf bn, int has_bn, int relu, int k, int s, int p,
+                                                               int PH, int PW, float* __restrict__ y,
+                                                               unsigned char* __restrict__ idx) {
+  const long long total = (long long)B * PH * PW * C4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    long long r = i / C4;
+    const int pw = (int)(r % PW); r /= PW;
+    const int ph = (int)(r % PH);
+    const int b = (int)(r / PH);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_bn) {
+      sc = *reinterpret_cast<const float4*>(bn.scale + c4 * 4);
+      sh = *reinterpret_cast<const float4*>(bn.shift + c4 * 4);
+    }
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 bi = make_uchar4(0, 0, 0, 0);
+    for (int kh = 0; kh < k; ++kh) {
+      const int h = ph * s - p + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int w = pw * s - p + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float4 v = reinterpret_cast<const float4*>(x)[(((long long)b * H + h) * W + w) * C4 + c4];
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const unsigned char id = (unsigned char)(kh * k + kw);
+        if (v.x > best.x) { best.x = v.x; bi.x = id; }
+        if (v.y > best.y) { best.y = v.y; bi.y = id; }
+        if (v.z > best.z) { best.z = v.z; bi.z = id; }
+        if (v.w > best.w) { best.w = v.w; bi.w = id; }
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = best;
+    if (idx) reinterpret_cast<uchar4*>(idx)[i] = bi;
+  }
+}
+
+int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
+                    float* y, unsigned char* idx, hipStream_t st) {
+  DIC_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+  const int PH = (H + 2 * p - k) / s + 1, PW = (W + 2 * p - k) / s + 1;
+  const long long total = (long long)B * PH * PW * (C / 4);
+  BnBuf z{};
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, B, H, W, C / 4, bn ? *bn : z,
+                     bn ? 1 : 0, relu, k, s, p, PH, PW, y, idx);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// adaptive average pooling to OUT x OUT (window [floor(i*H/OUT), ceil((i+1)*H/OUT)) )
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adaptive_avgpool_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
+                                                                BnBuf bn, int has_bn, int relu, int OUT,
+                                                                float* __restrict__ y) {
+  const long long total = (long long)B * OUT * OUT * C4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    long long r = i / C4;
+    const int oj = (int)(r % OUT); r /= OUT;
+    const int oi = (int)(r % OUT);
+    const int b = (int)(r / OUT);
+    const int h0 = (oi * H) / OUT, h1 = ((oi + 1) * H + OUT - 1) / OUT;
+    const int w0 = (oj * W) / OUT, w1 = ((oj + 1) * W + OUT - 1) / OUT;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_bn) {
+      sc = *reinterpret_cast<const float4*>(bn.scale + c4 * 4);
+      sh = *reinterpret_cast<const float4*>(bn.shift + c4 * 4);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) {
+        float4 v = reinterpret_cast<const float4*>(x)[(((long long)b * H + h) * W + w) * C4 + c4];
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    const float n = (float)((h1 - h0) * (w1 - w0));
+    acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n;
+    reinterpret_cast<float4*>(y)[i] = acc;
+  }
+}
+
+int adaptive_avgpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int out, float* y,
+                     hipStream_t st) {
+  DIC_REQUIRE(C % 4 == 0, "avgpool: C %% 4");
+  const long long total = (long long)B * out * out * (C / 4);
+  BnBuf z{};
+  hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, B, H, W, C / 4,
+                     bn ? *bn : z, bn ? 1 : 0, relu, out, y);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+__global__ void __launch_bounds__(256) adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, int B, int H, int W,
+                                                                    int C4, int OUT, float* __restrict__ dx) {
+  const long long total = (long long)B * H * W * C4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    long long r = i / C4;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int oi_lo = max(0, (h * OUT) / H - 1), oi_hi = min(OUT - 1, ((h + 1) * OUT + H - 1) / H + 1);
+    const int oj_lo = max(0, (w * OUT) / W - 1), oj_hi = min(OUT - 1, ((w + 1) * OUT + W - 1) / W + 1);
+    for (int oi = oi_lo; oi <= oi_hi; ++oi) {
+      const int h0 = (oi * H) / OUT, h1 = ((oi + 1) * H + OUT - 1) / OUT;
+      if (h < h0 || h >= h1) continue;
+      for (int oj = oj_lo; oj <= oj_hi; ++oj) {
+        const int w0 = (oj * W) / OUT, w1 = ((oj + 1) * W + OUT - 1) / OUT;
+        if (w < w0 || w >= w1) continue;
+        const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+        const float4 g = reinterpret_cast<const float4*>(dy)[(((long long)b * OUT + oi) * OUT + oj) * C4 + c4];
+        acc.x += g.x * inv; acc.y += g.y * inv; acc.z += g.z * inv; acc.w += g.w * inv;
+      }
+    }
+    reinterpret_cast<float4*>(dx)[i] = acc;
+  }
+}
+
+int adaptive_avgpool_bwd(const float* dy, int B, int H, int W, int C, int out, float* dx, hipStream_t st) {
+  const long long total = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, B, H, W, C / 4, out, dx);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward helpers
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_relu_bwd_kernel(const float* __restrict__ dpool,
+                                                                const unsigned char* __restrict__ idx,
+                                                                const float* __restrict__ x, int B, int H, int W, int C4,
+                                                                int k, int PH, int PW, BnBuf bn, float* __restrict__ dy) {
+  const long long total = (long long)B * H * W * C4;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    long long r = i / C4;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    const int ph = h / k, pw = w / k;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ph < PH && pw < PW) {
+      const long long po = (((long long)b * PH + ph) * PW + pw) * C4 + c4;
+      const float4 d = reinterpret_cast<const float4*>(dpool)[po];
+      const uchar4 id = reinterpret_cast<const uchar4*>(idx)[po];
+      const unsigned char me = (unsigned char)((h - ph * k) * k + (w - pw * k));
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c4 * 4);
+      const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c4 * 4);
+      g.x = (id.x == me && v.x * sc.x + sh.x > 0.f) ? d.x : 0.f;
+      g.y = (id.y == me && v.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+      g.z = (id.z == me && v.z * sc.z + sh.z > 0.f) ? d.z : 0.f;
+      g.w = (id.w == me && v.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+    }
+    reinterpret_cast<float4*>(dy)[i] = g;
+  }
+}
+
+int maxpool_relu_bwd(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
+                     BnBuf bn, float* dy, hipStream_t st) {
+  const long long total = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dpool, idx, x, B, H, W, C / 4,
+                     k, H / k, W / k, bn, dy);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+__global__ void __launch_bounds__(256) relu_mask_bwd_kernel(float* __restrict__ dy, const float* __restrict__ x,
+                                                             long long n4, int C4, BnBuf bn) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
+    float4 g = reinterpret_cast<float4*>(dy)[i];
+    if (!(v.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+    if (!(v.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+    if (!(v.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+    if (!(v.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+    reinterpret_cast<float4*>(dy)[i] = g;
+  }
+}
+
+int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hipStream_t st) {
+  const long long n4 = rows * C / 4;
+  hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy, x, n4, C / 4, bn);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// BatchNorm backward, stage 1: per (row-chunk, channel) sums of dy and dy*xhat.
+// block = 64 channels (16 float4 lanes) x 16 row lanes; grid (C/64, 64 chunks)
+constexpr int kBnChunks = 64;
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             long long rows, int C, BnBuf bn, float* __restrict__ part) {
+  __shared__ float4 sa[16][16], sb[16][16];
+  const int c4l = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4l * 4;
+  const long long per = (rows + kBnChunks - 1) / kBnChunks;
+  const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (c < C) {
+    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
+    for (long long r = r0 + rl; r < r1; r += 16) {
+      const float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
+      const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+      a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+      b.x += g.x * (v.x - mu.x) * is.x; b.y += g.y * (v.y - mu.y) * is.y;
+      b.z += g.z * (v.z - mu.z) * is.z; b.w += g.w * (v.w - mu.w) * is.w;
+    }
+  }
+  sa[rl][c4l] = a; sb[rl][c4l] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      a.x += sa[i][c4l].x; a.y += sa[i][c4l].y; a.z += sa[i][c4l].z; a.w += sa[i][c4l].w;
+      b.x += sb[i][c4l].x; b.y += sb[i][c4l].y; b.z += sb[i][c4l].z; b.w += sb[i][c4l].w;
+    }
+    *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * 2 + 0) * C + c) = a;
+    *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * 2 + 1) * C + c) = b;
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int C, double rows,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ k2, float* __restrict__ k3) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int t = 0; t < kBnChunks; ++t) {
+    a += (double)part[((long long)t * 2 + 0) * C + c];
+    b += (double)part[((long long)t * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)a;
+  dgamma[c] = (float)b;
+  k2[c] = (float)(a / rows);
+  k3[c] = (float)(b / rows);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ x,
+                                                            long long n4, int C4, const float* __restrict__ gamma,
+                                                            BnBuf bn, const float* __restrict__ k2,
+                                                            const float* __restrict__ k3) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    const float4 g = reinterpret_cast<float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 a2 = *reinterpret_cast<const float4*>(k2 + c);
+    const float4 a3 = *reinterpret_cast<const float4*>(k3 + c);
+    float4 o;
+    o.x = ga.x * is.x * (g.x - a2.x - (v.x - mu.x) * is.x * a3.x);
+    o.y = ga.y * is.y * (g.y - a2.y - (v.y - mu.y) * is.y * a3.y);
+    o.z = ga.z * is.z * (g.z - a2.z - (v.z - mu.z) * is.z * a3.z);
+    o.w = ga.w * is.w * (g.w - a2.w - (v.w - mu.w) * is.w * a3.w);
+    reinterpret_cast<float4*>(dy)[i] = o;
+  }
+}
+
+size_t bn_backward_ws_floats(int C) { return (size_t)kBnChunks * 2 * C + 2 * (size_t)C; }
+
+int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
+                float* dbeta, float* ws, hipStream_t st) {
+  DIC_REQUIRE(C % 64 == 0, "bn_backward: C %% 64");
+  float* part = ws;
+  float* k2 = ws + (size_t)kBnChunks * 2 * C;
+  float* k3 = k2 + C;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C / 64, kBnChunks), dim3(256), 0, st, dy_dx, x, rows, C, bn, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, C, (double)rows, dgamma,
+                     dbeta, k2, k3);
+  const long long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy_dx, x, n4, C / 4, gamma, bn, k2, k3);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// column sums with a fixed two-stage tree (deterministic)
+__global__ void __launch_bounds__(256) colsum_rows_kernel(const float* __restrict__ X, long long ld, long long rows,
+                                                           int C, float* __restrict__ out, int chunks) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long long per = (rows + chunks - 1) / chunks;
+  const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  for (long long r = r0; r < r1; ++r) s += X[r * ld + c];
+  out[(long long)blockIdx.y * C + c] = s;
+}
+
+int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st) {
+  const int chunks = (int)std::min<long long>(256, std::max<long long>(1, rows / 16));
+  if (chunks > 1) {
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), chunks), dim3(256), 0, st, X, ld, rows, C, ws, chunks);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, ws, (long long)C,
+                       (long long)chunks, C, out, 1);
+  } else {
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, X, ld, rows, C, out, 1);
+  }
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight layout transforms
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) oihw_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst, int O,
+                                                         int I, int KH, int KW, int to_ohwi) {
+  const long long total = (long long)O * I * KH * KW;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+    // e enumerates the OHWI order
+    const int i = (int)(e % I);
+    long long r = e / I;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH);
+    const int o = (int)(r / KH);
+    const long long oihw = (((long long)o * I + i) * KH + kh) * KW + kw;
+    if (to_ohwi) dst[e] = src[oihw];
+    else dst[oihw] = src[e];
+  }
+}
+
+int oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, hipStream_t st) {
+  const long long total = (long long)O * I * KH * KW;
+  hipLaunchKernelGGL(oihw_ohwi_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, src, dst, O, I, KH, KW, 1);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int ohwi_to_oihw(const float* src, float* dst, int O, int I, int KH, int KW, hipStream_t st) {
+  const long long total = (long long)O * I * KH * KW;
+  hipLaunchKernelGGL(oihw_ohwi_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, src, dst, O, I, KH, KW, 0);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+}  // namespace dic

@@ -185,3 +185,136 @@ def dropout_mask(shape, p: float, seed: int, offset: int, device) -> torch.Tenso
                               stream_ptr())
     check(rc, "dic_dropout_mask")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# depth encoder (dic_depth_encoder_fwd / _bwd)
+# ---------------------------------------------------------------------------------------------
+DEPTH_FIELDS = tuple((f"{layer}.{kind}", f"{layer}_{'w' if kind == 'weight' else 'b'}")
+                     for i in (1, 2, 3) for layer, kind in
+                     ((f"conv{i}", "weight"), (f"conv{i}", "bias"), (f"bn{i}", "weight"), (f"bn{i}", "bias")))
+
+
+class DepthPtrs(C.Structure):
+    """Mirrors dic_depth_encoder_weights / dic_depth_encoder_grads."""
+    _fields_ = [(f, C.c_void_p) for _, f in DEPTH_FIELDS]
+
+
+class DepthBnState(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in ("rm1", "rv1", "rm2", "rv2", "rm3", "rv3")]
+
+
+def depth_ptrs(tensors: Dict[str, torch.Tensor]):
+    keep, s = [], DepthPtrs()
+    for key, field in DEPTH_FIELDS:
+        t = _dev_f32(tensors[key], key)
+        keep.append(t)
+        setattr(s, field, t.data_ptr())
+    return s, keep
+
+
+@dataclass
+class DepthTape:
+    workspace: torch.Tensor
+    depth: torch.Tensor
+    weights: Dict[str, torch.Tensor]
+
+
+def depth_encoder_forward(weights: Dict[str, torch.Tensor], state: Dict[str, torch.Tensor], depth: torch.Tensor,
+                          train: bool, workspace: Optional[torch.Tensor] = None):
+    """dic_depth_encoder_fwd: depth [B,1,H,W] -> (features [B,196,2048], tape). `state` holds
+    bn{1,2,3}.running_{mean,var} (updated in place when train)."""
+    lib = _lib.load()
+    d = _dev_f32(depth, "depth_map")
+    B, c, H, W = d.shape
+    if c != 1:
+        raise _lib.DicError("depth map must be [B,1,H,W]")
+    wp, keep = depth_ptrs(weights)
+    st = DepthBnState()
+    for i in (1, 2, 3):
+        for short, name in (("rm", "running_mean"), ("rv", "running_var")):
+            t = state[f"bn{i}.{name}"]
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise _lib.DicError("BatchNorm running statistics must be contiguous fp32 GPU tensors")
+            setattr(st, f"{short}{i}", t.data_ptr())
+    lib.dic_depth_encoder_workspace_bytes.restype = C.c_size_t
+    need = lib.dic_depth_encoder_workspace_bytes(B, H, W)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=d.device)
+    out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=d.device)
+    rc = lib.dic_depth_encoder_fwd(C.byref(wp), C.byref(st), ptr(d), B, H, W, 1 if train else 0, ptr(out),
+                                   ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+    check(rc, "dic_depth_encoder_fwd")
+    return out, DepthTape(workspace, d, {k: t for (k, _), t in zip(DEPTH_FIELDS, keep)})
+
+
+def depth_encoder_backward(tape: DepthTape, d_features: torch.Tensor, grads: Optional[Dict[str, torch.Tensor]] = None):
+    lib = _lib.load()
+    if grads is None:
+        grads = {k: torch.empty_like(t) for k, t in tape.weights.items()}
+    gp, keep_g = depth_ptrs(grads)
+    wp, keep_w = depth_ptrs(tape.weights)
+    df = _dev_f32(d_features, "d_features")
+    B, _, H, W = tape.depth.shape
+    rc = lib.dic_depth_encoder_bwd(C.byref(wp), ptr(tape.depth), ptr(df), B, H, W, C.byref(gp), ptr(tape.workspace),
+                                   C.c_size_t(tape.workspace.numel()), stream_ptr())
+    check(rc, "dic_depth_encoder_bwd")
+    return grads
+
+
+# ---------------------------------------------------------------------------------------------
+# RGB encoder (dic_resnet_fwd)
+# ---------------------------------------------------------------------------------------------
+class ConvBnLayer(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in ("w", "gamma", "beta", "running_mean", "running_var")]
+
+
+class ResNetRunner:
+    """Holds the OHWI copies of the (frozen) ResNet conv weights and the layer table for dic_resnet_fwd.
+    `tensors` is keyed like CNNEncoder_Atten.state_dict() ('backbone.0.weight', 'backbone.1.running_mean', ...)."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor], layers: Sequence[int] = (3, 8, 36, 3)):
+        from .synthetic import resnet152_spec
+        lib = _lib.load()
+        self.blocks = (C.c_int * 4)(*[int(x) for x in layers])
+        self.spec = resnet152_spec(layers)
+        self.n_layers = len(self.spec)
+        self.table = (ConvBnLayer * self.n_layers)()
+        self.keep = []
+        for i, (key, bn, co, ci, k, _s, _p) in enumerate(self.spec):
+            w = _dev_f32(tensors[key], key)
+            if tuple(w.shape) != (co, ci, k, k):
+                raise _lib.DicError(f"{key}: expected {(co, ci, k, k)}, got {tuple(w.shape)}")
+            if k == 1 or ci == 1:
+                w_ohwi = w                               # same memory order
+            else:
+                w_ohwi = torch.empty_like(w)
+                check(lib.dic_oihw_to_ohwi(ptr(w), ptr(w_ohwi), co, ci, k, k, stream_ptr()), "dic_oihw_to_ohwi")
+            ent = self.table[i]
+            ent.w = w_ohwi.data_ptr()
+            tens = [w, w_ohwi]
+            for field, name in (("gamma", "weight"), ("beta", "bias"), ("running_mean", "running_mean"),
+                                ("running_var", "running_var")):
+                t = tensors[bn + name]
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                    raise _lib.DicError(f"{bn + name} must be a contiguous fp32 GPU tensor")
+                setattr(ent, field, t.data_ptr())
+                tens.append(t)
+            self.keep.append(tens)
+        self.workspace: Optional[torch.Tensor] = None
+
+    def forward(self, imgs: torch.Tensor, train_bn: bool) -> torch.Tensor:
+        lib = _lib.load()
+        x = _dev_f32(imgs, "imgs")
+        B, c, H, W = x.shape
+        if c != 3:
+            raise _lib.DicError("images must be [B,3,H,W]")
+        lib.dic_resnet_workspace_bytes.restype = C.c_size_t
+        need = lib.dic_resnet_workspace_bytes(B, H, W, self.blocks)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=x.device)
+        rc = lib.dic_resnet_fwd(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, ptr(out),
+                                ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
+        check(rc, "dic_resnet_fwd")
+        return out

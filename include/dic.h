@@ -115,6 +115,52 @@ int dic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp
  *      Philox4x32-10 counter-based stream keyed by (seed, offset). */
 int dic_dropout_mask(float* out, long long n, float p, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- depth encoder: Depth_CNN_endoder (Depth_caption_model/depth_models.py:12-56).
+ *      Weights in the reference's native layouts: conv*.weight OIHW, BatchNorm affine + running stats. */
+typedef struct dic_depth_encoder_weights {
+  const float *conv1_w, *conv1_b, *bn1_w, *bn1_b;   /* [128,1,7,7]   (depth_models.py:19-20) */
+  const float *conv2_w, *conv2_b, *bn2_w, *bn2_b;   /* [512,128,3,3] (:21-22) */
+  const float *conv3_w, *conv3_b, *bn3_w, *bn3_b;   /* [2048,512,1,1](:23-24) */
+} dic_depth_encoder_weights;
+typedef struct dic_depth_encoder_grads {
+  float *conv1_w, *conv1_b, *bn1_w, *bn1_b, *conv2_w, *conv2_b, *bn2_w, *bn2_b, *conv3_w, *conv3_b, *bn3_w, *bn3_b;
+} dic_depth_encoder_grads;
+typedef struct dic_depth_bn_state {                 /* running_mean / running_var, updated when train=1 */
+  float *rm1, *rv1, *rm2, *rv2, *rm3, *rv3;
+} dic_depth_bn_state;
+
+size_t dic_depth_encoder_workspace_bytes(int B, int H, int W);
+/* forward (depth_models.py:49-56): depth [B,1,H,W] -> features [B,196,2048]; train=1 uses batch
+ * statistics and updates the running stats, train=0 uses the running stats. */
+int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
+                          int H, int W, int train, float* features, void* workspace, size_t workspace_bytes,
+                          void* stream);
+/* backward of the train-mode forward above (same workspace): d_features [B,196,2048] -> 12 gradients
+ * (written, OIHW like the weights).  No input gradient: the depth map is detached (depth_train.py:204). */
+int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth, const float* d_features, int B, int H,
+                          int W, const dic_depth_encoder_grads* g, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ---- RGB encoder: CNNEncoder_Atten (Base_caption_model/base_caption_models.py:18-45) = torchvision
+ *      ResNet-152 (Bottleneck v1.5; blocks = {3,8,36,3}) minus fc, avgpool -> AdaptiveAvgPool2d(14).
+ *      Forward only (the reference runs it under @torch.no_grad).  One entry per conv+BN pair in
+ *      execution order (stem; per block conv1, conv2, conv3, then downsample for block 0 of a stage);
+ *      conv weights in OHWI (use dic_oihw_to_ohwi once on the reference's OIHW tensors). */
+typedef struct dic_conv_bn_layer {
+  const float* w;                 /* [CO][KH][KW][CI] */
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+} dic_conv_bn_layer;
+
+int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream);
+int dic_resnet_num_layers(const int* blocks);
+size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks);
+/* imgs [B,3,H,W] NCHW -> features [B,196,2048].  train_bn=1 reproduces quirk Q1 of the reference
+ * (encoder.train() at depth_train.py:161: batch statistics + running-stat updates in the frozen net);
+ * train_bn=0 is encoder.eval() (depth_train.py:242). */
+int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
+                   int H, int W, int train_bn, float* features, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
