@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the depth-soft captioner (224x224 RGB-D, seq-len 20).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full training iteration of depth_train.py:168-221 on one batch of synthetic inputs that are
+already resident in HBM: ResNet-152 forward (batch-statistics BN, quirk Q1) -> depth encoder forward ->
+decoder forward (T=20) -> CE + attention regulariser -> BPTT backward -> depth-encoder backward ->
+gradient all-reduce (N>1) -> AdamW.  Nothing is skipped inside the timed region.  Weak scaling: every rank
+processes --batch images per step (default 64 = BASELINE.json configs[1]); value = N*batch*K / max-rank time.
+
+The JSON line also carries
+  roofline     - the contraction kernel instantiation with the largest total time (per-launch HIP events on the
+                 launch stream, algorithmic FLOPs / measured time, peak = 157.3 TFLOP/s exact-fp32 MFMA),
+  cpu_baseline - the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+VOCAB = 10000
+SEQ_LEN = 20
+KIND_NAMES = {0: "rowk", 1: "colk", 2: "im2col", 3: "gather", 4: "im2col_colk", 5: "gather_colk"}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA (= vector fp32 peak)
+PEAK_HBM_TBS = 8.0
+
+
+def bytes_dec(B: int, T: int, V: int) -> float:
+    """Algorithmic HBM bytes of the decoder fwd+bwd+AdamW per iteration."""
+    L, D, A = 196, 2048, 128
+    return 4.0 * B * (2 * T * (L * D + L * A) + 5 * L * D + 4 * T * V) + 28.0 * (2248321 + 257 * V)
+
+
+def profile_step(trainer, args_step):
+    from depth_image_captioning_pub_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.dic_profile_begin(), "dic_profile_begin")
+    trainer.train_step(*args_step)
+    n = 64
+    keys = (C.c_int * n)()
+    ms = (C.c_double * n)()
+    fl = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    nout = C.c_int(0)
+    _lib.check(lib.dic_profile_end(n, keys, ms, fl, cnt, C.byref(nout)), "dic_profile_end")
+    rows = []
+    for i in range(nout.value):
+        k = keys[i]
+        tile = 128 if k >= 100 else 64
+        a, b = (k % 100) // 10, k % 10
+        rows.append({"kernel": f"gemm_kernel<{tile},{tile},{KIND_NAMES[a]},{KIND_NAMES[b]}>", "launches": int(cnt[i]),
+                     "total_ms": ms[i], "flops": fl[i]})
+    rows.sort(key=lambda r: -r["total_ms"])
+    return rows
+
+
+def cpu_baseline(sample_b: int, iters: int):
+    """Time the CPU oracle (port of the reference path) on the host cores: same step, same shapes."""
+    from depth_image_captioning_pub_amd import synthetic as syn
+    from oracle import captioning_oracle as orc
+    from depth_image_captioning_pub_amd.hostinfo import host_cores
+    cores = host_cores()                    # cgroup quota aware (the GPU box shows 256 CPUs, grants 16)
+    torch.set_num_threads(cores)
+    dec = syn.decoder_weights(VOCAB, seed=123)
+    enc, st = syn.depth_encoder_weights(seed=124)
+    rn = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(sample_b, seed=123)
+    depth = syn.depth_maps(sample_b, seed=123)
+    caps, lens = syn.captions_fixed(sample_b, VOCAB, SEQ_LEN, seed=123)
+    drop = syn.dropout_multiplier(sample_b, SEQ_LEN, 0.5, seed=123)
+    m = {k: torch.zeros_like(v) for k, v in {**dec, **enc}.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in {**dec, **enc}.items()}
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        feats = orc.resnet152_features(rn, imgs, train_bn=True)
+        loss, _, _, gd, ge = orc.train_step_soft(dec, enc, st, feats, depth, caps, lens, drop)
+        params = {**dec, **enc}
+        orc.adamw_step(params, {**gd, **ge}, m, v2, step=it + 1)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": sample_b / t, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} timed + 1 warm-up full training steps of the CPU oracle (ResNet-152 fwd + depth encoder "
+                      f"fwd/bwd + decoder fwd/bwd + AdamW) on batch {sample_b}, seq-len {SEQ_LEN}, V={VOCAB}, "
+                      f"median {t:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
+                                             device_id=torch.device(dev))
+        pg = torch.distributed.group.WORLD
+
+    from depth_image_captioning_pub_amd import build as dic_build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        if local == 0:
+            dic_build.build()
+        if world > 1:
+            torch.distributed.barrier()
+    from depth_image_captioning_pub_amd import synthetic as syn
+    from depth_image_captioning_pub_amd.engine import CaptionTrainer
+
+    B = args.batch
+    trainer = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg)
+    imgs = syn.rgb_images(B, seed=123 + rank).to(dev)
+    depth = syn.depth_maps(B, seed=123 + rank).to(dev)
+    caps, lens = syn.captions_fixed(B, VOCAB, SEQ_LEN, seed=123 + rank)
+    caps = caps.to(dev)
+    step_args = (imgs, depth, caps, lens)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = trainer.train_step(*step_args)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(*step_args)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    # ---- per-stage and per-kernel measurements: two extra steps after the timed region (every rank runs
+    #      them so the collectives stay matched) ----
+    trainer.timing = (rank == 0)
+    trainer.train_step(*step_args)
+    torch.cuda.synchronize()
+    stages = {k: round(v, 3) for k, v in trainer.stage_ms().items()} if rank == 0 else {}
+    trainer.timing = False
+    prof = None
+    if rank == 0:
+        prof = profile_step(trainer, step_args)
+    else:
+        trainer.train_step(*step_args)
+    ms_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    result = None
+    if rank == 0:
+        top = prof[0]
+        ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": top["launches"],
+                    "avg_launch_us": round(top["total_ms"] * 1e3 / top["launches"], 2),
+                    "all_contraction_kernels": [
+                        {"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
+                         "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2)} for r in prof]}
+        dec_ms = sum(stages.get(k, 0.0) for k in ("decoder_fwd", "loss", "decoder_bwd", "adamw"))
+        dec_bw = bytes_dec(B, SEQ_LEN, VOCAB) / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else 0.0
+        decoder_roofline = {"bound": "hbm", "stage": "decoder fwd + loss + BPTT bwd + AdamW", "ms": round(dec_ms, 3),
+                            "algorithmic_bytes": bytes_dec(B, SEQ_LEN, VOCAB), "achieved": round(dec_bw, 3),
+                            "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": round(dec_bw / PEAK_HBM_TBS, 4)}
+        result = {
+            "metric": "images/sec (train, depth-soft, 224x224, seq-len 20)", "value": round(value, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"depth-soft train step, synthetic RGB-D 224x224, batch {B}/GPU, seq-len {SEQ_LEN}, "
+                                   f"V={VOCAB}, ResNet-152 (random init, batch-stat BN) + depth CNN + soft-attention LSTM",
+                       "global_batch": world * B, "batch_per_gpu": B, "seq_len": SEQ_LEN, "vocab": VOCAB,
+                       "parallelism": f"dp{world}"},
+            "loss": round(loss_val, 5), "stages_ms": stages, "roofline": roofline, "decoder_roofline": decoder_roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

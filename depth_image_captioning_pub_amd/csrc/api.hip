@@ -32,4 +32,10 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
   return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile);
 }
 
+int dic_profile_begin(void) { return gemm_profile_begin(); }
+int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
+  DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");
+  return gemm_profile_end(max_entries, keys, total_ms, total_flops, launches, n_out);
+}
+
 }  // extern "C"

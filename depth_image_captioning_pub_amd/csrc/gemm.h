@@ -71,6 +71,8 @@ GemmOperand op_im2col(const float* x, const ConvGeom& g);
 GemmOperand op_gather(const float* x, const ConvGeom& g);
 GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
 GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
+int gemm_profile_begin();
+int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
 GemmEpilogue ep_store(float* C, long long ldc, const float* bias = nullptr, int act = ACT_NONE);
 
 // convenience: C = A(MxK, rowk) * B(NxK, rowk)^T etc. with automatic split-K for skinny shapes

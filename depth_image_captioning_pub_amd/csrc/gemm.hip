@@ -1,5 +1,8 @@
 // Exact-fp32 MFMA GEMM / implicit-GEMM convolution kernel for gfx950 (see gemm.h).
 #include "gemm.h"
+#include <algorithm>
+#include <map>
+#include <vector>
 
 namespace dic {
 
@@ -351,6 +354,49 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Optional per-launch timing (bench.py roofline): HIP events recorded on the launch stream around
+// every contraction launch, summed per kernel instantiation (tile, A kind, B kind).
+struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int gemm_profile_begin() {
+  for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof_recs.clear();
+  g_prof_on = true;
+  return DIC_OK;
+}
+
+int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
+  g_prof_on = false;
+  DIC_CHECK_HIP(hipDeviceSynchronize());
+  std::map<int, int> slot;
+  int n = 0;
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    DIC_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    auto it = slot.find(r.key);
+    int i;
+    if (it == slot.end()) {
+      if (n >= max_entries) continue;
+      i = n++; slot[r.key] = i; keys[i] = r.key; total_ms[i] = 0; total_flops[i] = 0; launches[i] = 0;
+    } else i = it->second;
+    total_ms[i] += ms; total_flops[i] += r.flops; launches[i] += 1;
+  }
+  for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof_recs.clear();
+  *n_out = n;
+  return DIC_OK;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 GemmOperand op_rowk(const float* p, long long ld) {
@@ -439,9 +485,20 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     DIC_REQUIRE(p.ep.stats == nullptr, "gemm: BN statistics epilogue cannot be combined with split-K");
   }
   if (p.ep.alpha == 0.0f) p.ep.alpha = 1.0f;
+  ProfRec rec{};
+  if (g_prof_on) {
+    rec.e0 = prof_event(); rec.e1 = prof_event();
+    rec.flops = 2.0 * p.M * p.N * (double)p.K;
+    rec.key = (tile == 128 ? 100 : 0) + p.A.kind * 10 + p.B.kind;
+    (void)hipEventRecord(rec.e0, st);
+  }
   int rc = (tile == 128) ? launch_tile<128, 128>(p, st) : launch_tile<64, 64>(p, st);
   if (rc != 0) return rc;
   DIC_LAUNCH_CHECK();
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof_recs.push_back(rec);
+  }
   if (p.splitk > 1 && !p.raw_partials) {
     const long long total = (long long)p.M * p.N;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);

@@ -1,0 +1,198 @@
+"""Fused depth-soft / depth-hard training step on one MI355X, data-parallel across the GPUs of a node.
+
+Counterpart of the inner loop of train_Cdepth_soft / train_Cdepth_hard
+(Captioning_models/Depth_caption_model/depth_train.py:168-229, 500-560): same call order, same
+train/eval-mode semantics (incl. quirk Q1: the frozen ResNet normalises with batch statistics while
+training), same loss, same AdamW update - every tensor operation runs in libdic_hip.so.
+
+Data parallelism (not in the reference): one process per GPU, each rank takes a slice of
+the batch; the 29 gradient tensors live in one flat fp32 buffer that is all-reduced (sum of gradients that
+were pre-scaled by 1/world_size) with RCCL over xGMI - the decoder bucket is launched as soon as BPTT ends and
+overlaps the depth-encoder backward; BatchNorm statistics stay per rank (DDP semantics).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import native, synthetic as syn
+from ._lib import DicError
+
+ALIGN = 64   # floats: every parameter slice starts 256-B aligned so the GEMM loaders can use 16-B vectors
+
+
+class FlatParams:
+    """One flat fp32 buffer holding a list of named tensors as aligned views (+ twin buffers for grads / Adam)."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor], device):
+        self.names: List[str] = list(tensors)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for k in self.names:
+            self.offsets[k] = off
+            off += (tensors[k].numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.data)
+        self.exp_avg = torch.zeros_like(self.data)
+        self.exp_avg_sq = torch.zeros_like(self.data)
+        self.shapes = {k: tuple(tensors[k].shape) for k in self.names}
+        for k in self.names:
+            self.view(self.data, k).copy_(tensors[k].to(device))
+
+    def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        n = 1
+        for s in self.shapes[name]:
+            n *= s
+        return buf[o:o + n].view(self.shapes[name])
+
+    def views(self, buf: torch.Tensor, names: Optional[Sequence[str]] = None) -> Dict[str, torch.Tensor]:
+        return {k: self.view(buf, k) for k in (names or self.names)}
+
+    def span(self, names: Sequence[str]):
+        """[start, end) of the contiguous run covering `names` (must be adjacent in the flat buffer)."""
+        lo = self.offsets[names[0]]
+        last = names[-1]
+        n = 1
+        for s in self.shapes[last]:
+            n *= s
+        hi = (self.offsets[last] + n + ALIGN - 1) // ALIGN * ALIGN
+        return lo, min(hi, self.total)
+
+
+class CaptionTrainer:
+    """Owns weights, optimiser state and workspaces of one rank and runs fused train steps."""
+
+    def __init__(self, vocab: int, device: str = "cuda:0", seed: int = 123, lr: float = 1e-3, hard: bool = False,
+                 resnet_layers: Sequence[int] = (3, 8, 36, 3), dropout: float = 0.5, lam: float = 0.7,
+                 decoder_init: Optional[Dict[str, torch.Tensor]] = None,
+                 depth_init: Optional[Dict[str, torch.Tensor]] = None,
+                 depth_state: Optional[Dict[str, torch.Tensor]] = None,
+                 resnet_init: Optional[Dict[str, torch.Tensor]] = None,
+                 process_group=None):
+        if not torch.cuda.is_available():
+            raise DicError("CaptionTrainer needs a GPU: the product path has no CPU fallback")
+        self.device = torch.device(device)
+        self.vocab, self.lr, self.hard, self.p_drop, self.lam = vocab, lr, hard, dropout, lam
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        dec = decoder_init if decoder_init is not None else syn.decoder_weights(vocab, seed=seed)
+        if depth_init is None:
+            depth_init, depth_state = syn.depth_encoder_weights(seed=seed + 1)
+        rn = resnet_init if resnet_init is not None else syn.resnet152_weights(seed=seed + 2, layers=resnet_layers)
+        self.dec_names = [k for k, _ in native.DECODER_FIELDS]
+        self.enc_names = [k for k, _ in native.DEPTH_FIELDS]
+        merged = {("decoder." + k): dec[k] for k in self.dec_names}
+        merged.update({("depth_encoder." + k): depth_init[k] for k in self.enc_names})
+        self.flat = FlatParams(merged, self.device)
+        self.dec_w = {k: self.flat.view(self.flat.data, "decoder." + k) for k in self.dec_names}
+        self.enc_w = {k: self.flat.view(self.flat.data, "depth_encoder." + k) for k in self.enc_names}
+        self.dec_g = {k: self.flat.view(self.flat.grad, "decoder." + k) for k in self.dec_names}
+        self.enc_g = {k: self.flat.view(self.flat.grad, "depth_encoder." + k) for k in self.enc_names}
+        self.dec_span = self.flat.span(["decoder." + k for k in self.dec_names])
+        self.enc_span = self.flat.span(["depth_encoder." + k for k in self.enc_names])
+        self.enc_state = {k: v.to(self.device).contiguous() for k, v in depth_state.items()}
+        self.rn_w = {k: v.to(self.device).contiguous() for k, v in rn.items()}
+        self.resnet = native.ResNetRunner(self.rn_w, resnet_layers)
+        self.step_count = 0
+        self.rng_offset = 0
+        self.seed = seed
+        self.dec_ws: Optional[torch.Tensor] = None
+        self.enc_ws: Optional[torch.Tensor] = None
+        self.last = {}
+        self.keep_outputs = False      # True: keep logits intact (loss gradient not written in place)
+        self.timing = False            # True: record stage-boundary events on the current stream
+        self.marks = []
+
+    def _mark(self, name: str) -> None:
+        if self.timing:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
+    def stage_ms(self) -> Dict[str, float]:
+        """Elapsed ms between consecutive stage marks of the last timed step (call after a synchronize)."""
+        out: Dict[str, float] = {}
+        for (_, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+    # ---- pieces -----------------------------------------------------------------------------
+    def encode(self, imgs: torch.Tensor, depth_map: torch.Tensor, train: bool):
+        feats = self.resnet.forward(imgs, train_bn=train)                                   # depth_train.py:179
+        fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), train,
+                                                   workspace=self.enc_ws)                    # :204-206
+        self.enc_ws = dtape.workspace
+        return feats, fdep, dtape
+
+    def train_step(self, imgs: torch.Tensor, depth_map: torch.Tensor, captions: torch.Tensor, lengths: Sequence[int],
+                   drop_mult: Optional[torch.Tensor] = None, gumbel_u: Optional[torch.Tensor] = None,
+                   temp: float = 1.0, precomputed_features: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync)."""
+        B = imgs.shape[0] if imgs is not None else precomputed_features.shape[0]
+        tmax = max(lengths) - 1
+        self.marks = []
+        self._mark("start")
+        if precomputed_features is None:
+            feats = self.resnet.forward(imgs, train_bn=True)                                # depth_train.py:179
+            self._mark("resnet152_fwd")
+            fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
+                                                       workspace=self.enc_ws)               # :204-206
+            self.enc_ws = dtape.workspace
+        else:                                       # decoder/depth-encoder-only step (tests)
+            feats = precomputed_features
+            fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
+                                                       workspace=self.enc_ws)
+            self.enc_ws = dtape.workspace
+        self._mark("depth_encoder_fwd")
+        if drop_mult is None and self.p_drop > 0:
+            drop_mult = native.dropout_mask((B, tmax, native.D_HID), self.p_drop, self.seed, self.rng_offset, self.device)
+            self.rng_offset += B * tmax * native.D_HID // 4 + 1
+        mode = 1 if self.hard else 0
+        logits, alphas, tape = native.decoder_forward(self.dec_w, feats, fdep, captions, lengths, drop_mult, mode=mode,
+                                                      gumbel_u=gumbel_u, temp=temp, workspace=self.dec_ws)
+        self.dec_ws = tape.workspace
+        self._mark("decoder_fwd")
+        targets = native.pack_targets(captions, lengths)                                     # :210-213
+        loss, dlogits, dalphas = native.caption_loss(logits, targets, None if self.hard else alphas, self.lam,
+                                                     grad_scale=1.0 / self.world,
+                                                     in_place=not self.keep_outputs)         # :214-216
+        self._mark("loss")
+        _, dfeat = native.decoder_backward(tape, dlogits, dalphas, grads=self.dec_g)         # :219
+        self._mark("decoder_bwd")
+        work = []
+        if self.world > 1:   # decoder bucket goes out while the depth-encoder backward still runs
+            lo, hi = self.dec_span
+            work.append(torch.distributed.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
+        native.depth_encoder_backward(dtape, dfeat, grads=self.enc_g)
+        if self.world > 1:
+            lo, hi = self.enc_span
+            work.append(torch.distributed.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
+            for w in work:
+                w.wait()
+        self._mark("depth_encoder_bwd+allreduce")
+        self.step_count += 1
+        native.adamw_step(self.flat.data, self.flat.grad, self.flat.exp_avg, self.flat.exp_avg_sq, self.step_count,
+                          lr=self.lr)                                                        # :221
+        self._mark("adamw")
+        self.last = {"logits": logits, "alphas": alphas, "features": feats, "depth_features": fdep}
+        return loss
+
+    @torch.no_grad()
+    def eval_loss(self, imgs, depth_map, captions, lengths) -> torch.Tensor:
+        """Validation forward (depth_train.py:248-292): eval-mode BN in both encoders, dropout off."""
+        feats, fdep, _ = self.encode(imgs, depth_map, train=False)
+        logits, alphas, tape = native.decoder_forward(self.dec_w, feats, fdep, captions, lengths, None,
+                                                      workspace=self.dec_ws)
+        self.dec_ws = tape.workspace
+        loss, _, _ = native.caption_loss(logits, native.pack_targets(captions, lengths), alphas, self.lam)
+        return loss
+
+    def state_dicts(self):
+        """Reference-compatible state_dict contents (keys as in SURVEY.md section 8b) for checkpointing."""
+        dec = {k: v.detach().clone() for k, v in self.dec_w.items()}
+        enc = {k: v.detach().clone() for k, v in self.enc_w.items()}
+        enc.update({k: v.detach().clone() for k, v in self.enc_state.items()})
+        return {"decoder": dec, "depth_encoder": enc, "encoder": {k: v.detach().clone() for k, v in self.rn_w.items()}}

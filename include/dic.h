@@ -161,6 +161,12 @@ size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks);
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
                    int H, int W, int train_bn, float* features, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- measurement aid (bench.py roofline): per-launch HIP events around every MFMA contraction launch,
+ *      recorded on the launch stream; dic_profile_end synchronises and returns, per kernel instantiation
+ *      (key = 100*(tile==128) + 10*A_kind + B_kind), total milliseconds, algorithmic FLOPs and launches. */
+int dic_profile_begin(void);
+int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

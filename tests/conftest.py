@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    import torch
+    from depth_image_captioning_pub_amd.hostinfo import host_cores
+    torch.set_num_threads(host_cores())      # the GPU box exposes 256 CPUs but grants a 16-CPU quota
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
