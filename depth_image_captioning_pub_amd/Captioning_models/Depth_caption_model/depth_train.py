@@ -1,0 +1,101 @@
+"""Training harness with the reference's entry points train_Cdepth_soft(ext, useData) /
+train_Cdepth_hard(ext, useData) (Captioning_models/Depth_caption_model/depth_train.py:27-325, 338-643) and
+temp_anneal (:329-336).
+
+The reference's COCO / "original" data pipelines (torchvision CocoCaptions + collate, util.py:52-221), its DPT
+depth front-end and its vocabulary pickle are out of scope of this build and not present
+offline, so `useData` additionally accepts "synthetic": procedurally generated RGB-D batches of the reference's
+shapes.  The loop itself keeps the reference's structure: per-iteration fused train step (= depth_train.py:168-221),
+per-epoch validation in eval mode (:238-303), loss CSVs (:232-233,302-303) and best-validation checkpoints of the
+three state_dicts with the reference's file names (:306-322)."""
+from __future__ import annotations
+
+import os
+from collections import deque
+
+import numpy as np
+import torch
+
+from ... import synthetic as syn
+from ..._lib import DicError
+from ...engine import CaptionTrainer
+from ..config import ConfigTrain
+
+lam = 0.7             # depth_train.py:25
+tqdm_disable = True   # depth_train.py:24
+
+
+def temp_anneal(epoch_num):
+    """temp = max(cos(pi * epoch / 360), 0.5) as a float32 tensor (depth_train.py:329-336)."""
+    temp = np.array(np.cos(np.pi * (epoch_num / 360)))
+    if temp <= 0.5:
+        temp = np.array(0.5)
+    return torch.from_numpy(temp.astype(np.float32)).clone()
+
+
+def _synthetic_batches(config, rank: int, n: int, seed0: int):
+    for i in range(n):
+        s = seed0 + 7919 * i + rank
+        imgs = syn.rgb_images(config.batch_size, seed=s)
+        depth = syn.depth_maps(config.batch_size, seed=s)
+        caps, lens = syn.captions_fixed(config.batch_size, config.vocab_size, config.seq_len, seed=s)
+        yield imgs, depth, caps, lens
+
+
+def _train(ext, useData, hard: bool, config=None, process_group=None):
+    config = config or ConfigTrain()
+    if useData != "synthetic":
+        raise DicError(f"useData={useData!r}: the MSCOCO / original-dataset loaders, the vocabulary pickle and the DPT "
+                       "depth front-end are outside this build's scope (SURVEY.md 8f) and not available offline; "
+                       "use useData='synthetic'")
+    save_directory = config.save_directory_Cdep_hard if hard else config.save_directory_Cdep_soft
+    os.makedirs(save_directory, exist_ok=True)
+    tag = "depth_hard" if hard else "depth_soft"
+    train_loss_file = f"{save_directory}/{tag}_train_loss_{useData}{ext}.csv"
+    val_loss_file = f"{save_directory}/{tag}_val_loss_{useData}{ext}.csv"
+    rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+    trainer = CaptionTrainer(config.vocab_size, device=config.device, seed=123 + int(ext), lr=config.lr, hard=hard,
+                             dropout=config.dropout, lam=lam, process_group=process_group)
+    dev = config.device
+    temp = torch.tensor(1.0)
+    val_loss_best = float("inf")
+    history = []
+    for epoch in range(config.num_epochs):
+        if hard and epoch % config.temp_sch == 0:                       # depth_train.py:481-483
+            temp = temp_anneal(epoch)
+        window, losses = deque(), []
+        for imgs, depth, caps, lens in _synthetic_batches(config, rank, config.iters_per_epoch, 1000 * epoch):
+            u = syn.gumbel_uniforms(max(lens) - 1, len(lens), seed=epoch).to(dev) if hard else None
+            loss = trainer.train_step(imgs.to(dev), depth.to(dev), caps.to(dev), lens, gumbel_u=u, temp=float(temp))
+            losses.append(loss)                                         # device tensors: no per-iteration host sync
+            window.append(loss)
+            if len(window) > config.moving_avg:
+                window.popleft()
+        train_loss = float(torch.stack(losses).mean().item())
+        if rank == 0:
+            with open(train_loss_file, "a") as f:
+                print(f"{epoch}, {train_loss}", file=f)
+        val_losses = []
+        if not hard:
+            for imgs, depth, caps, lens in _synthetic_batches(config, rank, max(1, config.iters_per_epoch // 4), 777):
+                val_losses.append(trainer.eval_loss(imgs.to(dev), depth.to(dev), caps.to(dev), lens))
+        val_loss = float(torch.stack(val_losses).mean().item()) if val_losses else train_loss
+        history.append((train_loss, val_loss))
+        if rank == 0:
+            with open(val_loss_file, "a") as f:
+                print(f"{epoch}, {val_loss}", file=f)
+            if val_loss < val_loss_best:                                # depth_train.py:306-322
+                val_loss_best = val_loss
+                sd = trainer.state_dicts()
+                torch.save(sd["encoder"], f"{save_directory}/{tag}_encoder_best_{useData}{ext}.pth")
+                torch.save(sd["decoder"], f"{save_directory}/{tag}_decoder_best_{useData}{ext}.pth")
+                torch.save(sd["depth_encoder"], f"{save_directory}/{tag}_D_encoder_best_{useData}{ext}.pth")
+    return history
+
+
+def train_Cdepth_soft(ext, useData, config=None, process_group=None):
+    return _train(ext, useData, hard=False, config=config, process_group=process_group)
+
+
+def train_Cdepth_hard(ext, useData, config=None, process_group=None):
+    return _train(ext, useData, hard=True, config=config, process_group=process_group)

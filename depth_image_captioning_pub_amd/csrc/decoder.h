@@ -23,6 +23,8 @@ struct DecoderWs {
   float *dHd, *dG, *slab_dx, *dctx, *dgpre, *dq, *dalp, *pbeta, *dqp, *dwf_acc, *dbf_acc, *dPacc, *carry_dc;
   float *dinit, *dmean, *colsum_ws;
   int* dlen;
+  float* logits_step;
+  long long* ids;
   size_t gemm_ws_floats;
   size_t bytes;
 };

@@ -61,6 +61,8 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.dmean = c.take<float>((size_t)B * kD);
   w.colsum_ws = c.take<float>((size_t)64 * std::max(std::max(V, kD), kXK));
   w.dlen = c.take<int>((size_t)B);
+  w.logits_step = c.take<float>((size_t)B * V);
+  w.ids = c.take<long long>((size_t)B);
   w.bytes = c.off;
   if (overflow) *overflow = c.overflow;
   return w;
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(
     const float* __restrict__ b_full, const float* __restrict__ WbT, const float* __restrict__ b_beta,
     int t, int T, int mode, const float* __restrict__ gumbel_u, int B, float temp,
     float* __restrict__ alphas, float* __restrict__ Qall, float* __restrict__ ctx_all,
-    float* __restrict__ gate_all, float* __restrict__ Xall) {
+    float* __restrict__ gate_all, float* __restrict__ Xall, int do_gate) {
   __shared__ float h_s[kH];
   __shared__ float q_s[2][kA];
   __shared__ float e_s[kL + 4];
@@ -197,9 +199,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(
   if (tid < kA) {
     const float q = b_h[tid] + q_s[0][tid] + q_s[1][tid];
     q_s[0][tid] = q;
-    if (chunk == 0) Qall[bt * kA + tid] = q;
+    if (chunk == 0 && Qall) Qall[bt * kA + tid] = q;
   }
-  if (chunk == 0 && tid < kH) Xall[bt * kXK + kE + kD + tid] = h_s[tid];   // h_prev slot of the LSTM input
+  if (chunk == 0 && tid < kH && Xall) Xall[bt * kXK + kE + kD + tid] = h_s[tid];   // h_prev slot of the LSTM input
   __syncthreads();
   {  // e[l] = w . relu(P[l,:] + q) + b : one 32-lane half-wave per cell, float4 per lane
     const int l32 = lane & 31, sub = lane >> 5;
@@ -273,6 +275,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(
   {  // gate = sigmoid(W_beta h + b) ; x = gate * ctx          (depth_models.py:189-190)
     const int d = chunk * 256 + tid;
     const float c = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
+    if (!do_gate) {            // stand-alone Soft/Hard_Attention.forward: context vector only
+      ctx_all[bt * kD + d] = c;
+      return;
+    }
     float s = b_beta[d];
 #pragma unroll 8
     for (int k = 0; k < kH; ++k) s += WbT[(long long)k * kD + d] * h_s[k];
@@ -544,6 +550,51 @@ __global__ void __launch_bounds__(256) dF_init_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// greedy decoding helpers (batch_sample / sample, depth_models.py:216-305): everything stays on the device
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fill_ids_kernel(long long* ids, int n, long long v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) ids[i] = v;
+}
+
+__global__ void __launch_bounds__(kE) embed_step_kernel(const float* __restrict__ embed, const long long* __restrict__ ids,
+                                                         int t, int T, int V, float* __restrict__ Xall) {
+  const int b = blockIdx.x;
+  long long id = ids[b];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  Xall[((long long)b * T + t) * kXK + threadIdx.x] = embed[id * kE + threadIdx.x];
+}
+
+// ids[b] = argmax_v logits[b,v] (first maximum on ties, like torch.argmax); also out[b*T + t]
+__global__ void __launch_bounds__(256) argmax_kernel(const float* __restrict__ logits, int V, int t, int T,
+                                                      long long* __restrict__ ids, long long* __restrict__ out) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* x = logits + (long long)b * V;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const float f = x[v];
+    if (f > best) { best = f; idx = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+  }
+  if (lane == 0) { bv[w] = best; bi[w] = idx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 4; ++i)
+      if (bv[i] > best || (bv[i] == best && bi[i] < idx)) { best = bv[i]; idx = bi[i]; }
+    ids[b] = idx;
+    out[(long long)b * T + t] = idx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
 struct StepPlan {
@@ -651,7 +702,7 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
     const int nb = pl.bs[t];
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, nb), dim3(256), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
                        w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, temp, alphas,
-                       ws.Qall, ws.ctx, ws.gate, ws.Xall);
+                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
     DIC_LAUNCH_CHECK();
     DIC_TRY(gemm_slabs(nb, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
@@ -762,6 +813,91 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
     ep.accumulate = 1;
     DIC_TRY(gemm(B * kL, kD, kA, op_rowk(ws.dPacc, kA), op_colk(w->enc_att_w, kD), ep, st));
   }
+  return DIC_OK;
+}
+
+size_t dic_decoder_greedy_workspace_bytes(int B, int max_length, int V) {
+  bool ov;
+  return decoder_carve(nullptr, 0, B, max_length, V, B * max_length, &ov).bytes;
+}
+
+int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth, int B,
+                       long long id_start, int max_length, int mode, const float* gumbel_u, int64_t* out_ids,
+                       float* alphas_out, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_TRY(check_common(w, V, B, workspace));
+  DIC_REQUIRE(feat_rgb && out_ids && max_length >= 1, "decoder_greedy: bad arguments");
+  DIC_REQUIRE(mode == 0 || mode == 2, "decoder_greedy: mode must be 0 (soft) or 2 (Gumbel-max hard attention)");
+  DIC_REQUIRE(mode == 0 || gumbel_u != nullptr, "decoder_greedy: hard attention needs the uniform draws");
+  const int T = max_length, N = B * T;
+  bool ov = false;
+  DecoderWs ws = decoder_carve(workspace, workspace_bytes, B, T, V, N, &ov);
+  DIC_REQUIRE(!ov, "decoder_greedy: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+  float* alphas = alphas_out ? alphas_out : ws.dalp;     // [B,T,196] needed by the step kernel; dalp is [8,B,196]
+  if (!alphas_out) DIC_REQUIRE(T <= kNCH, "decoder_greedy: alphas_out required when max_length > %d", kNCH);
+  hipLaunchKernelGGL(pack_lstm_kernel, dim3(kG), dim3(256), 0, st, w->w_ih, w->w_hh, w->b_ih, w->b_hh, ws.Wcat, ws.bcat);
+  DIC_TRY(launch_transpose(w->dec_att_w, ws.WhT, kA, kH, st));
+  DIC_TRY(launch_transpose(w->fbeta_w, ws.WbT, kD, kH, st));
+  hipLaunchKernelGGL(fuse_mean_kernel, dim3(kNCH, B), dim3(256), 0, st, feat_rgb, feat_depth, ws.F, ws.mean);
+  DIC_LAUNCH_CHECK();
+  DIC_TRY(gemm(B * kL, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st));
+  {
+    GemmEpilogue ep = ep_store(ws.Hall, (long long)(T + 1) * kH, w->init_b);
+    ep.C2 = ws.Call; ep.ldc2 = (long long)(T + 1) * kH; ep.nsplit = kH;
+    DIC_TRY(gemm(B, 2 * kH, kD, op_rowk(ws.mean, kD), op_rowk(w->init_w, kD), ep, st, 16, ws.gemm_ws, 64));
+  }
+  hipLaunchKernelGGL(fill_ids_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, st, ws.ids, B, id_start);
+  DIC_LAUNCH_CHECK();
+  for (int t = 0; t < T; ++t) {
+    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(kE), 0, st, w->embed, ws.ids, t, T, V, ws.Xall);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(256), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
+                       w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, 1.0f, alphas,
+                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
+    DIC_LAUNCH_CHECK();
+    DIC_TRY(gemm_slabs(B, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
+                       ws.slab_g, kS_LSTM, st));
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B), dim3(kH), 0, st, ws.slab_g, kS_LSTM, B, ws.bcat, t, T,
+                       (const float*)nullptr, t * B, ws.Hall, ws.Call, ws.Gact, ws.Hdrop);
+    DIC_LAUNCH_CHECK();
+    // pred = linear(h) (no dropout, depth_models.py:295); softmax is monotone -> argmax of the logits
+    DIC_TRY(gemm(B, V, kH, op_rowk(ws.Hdrop + (long long)t * B * kH, kH), op_rowk(w->out_w, kH),
+                 ep_store(ws.logits_step, V, w->out_b), st, 1, nullptr, 64));
+    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, st, ws.logits_step, V, t, T, ws.ids, (long long*)out_ids);
+    DIC_LAUNCH_CHECK();
+  }
+  return DIC_OK;
+}
+
+size_t dic_attention_workspace_bytes(int B) {
+  Carver c(nullptr, 0);
+  c.take<float>((size_t)B * kL * kA);
+  c.take<float>((size_t)kH * kA);
+  c.take<float>((size_t)B * 2 * kH);
+  return c.off;
+}
+
+int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const float* dec_att_w, const float* dec_att_b,
+                      const float* full_att_w, const float* full_att_b, const float* feats, const float* h, int B,
+                      int mode, const float* gumbel_u, float temp, float* ctx, float* alpha, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(enc_att_w && enc_att_b && dec_att_w && dec_att_b && full_att_w && full_att_b && feats && h && ctx &&
+                  alpha && workspace && B > 0, "attention_fwd: bad arguments");
+  DIC_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || gumbel_u), "attention_fwd: bad mode / missing uniform draws");
+  DIC_REQUIRE(workspace_bytes >= dic_attention_workspace_bytes(B), "attention_fwd: workspace too small");
+  Carver c(workspace, workspace_bytes);
+  float* P = c.take<float>((size_t)B * kL * kA);
+  float* WhT = c.take<float>((size_t)kH * kA);
+  float* H2 = c.take<float>((size_t)B * 2 * kH);
+  DIC_CHECK_HIP(hipMemcpy2DAsync(H2, 2 * kH * sizeof(float), h, kH * sizeof(float), kH * sizeof(float), B,
+                                 hipMemcpyDeviceToDevice, st));
+  DIC_TRY(launch_transpose(dec_att_w, WhT, kA, kH, st));
+  DIC_TRY(gemm(B * kL, kA, kD, op_rowk(feats, kD), op_rowk(enc_att_w, kD), ep_store(P, kA, enc_att_b), st));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(256), 0, st, feats, (const float*)P, (const float*)H2,
+                     (const float*)WhT, dec_att_b, full_att_w, full_att_b, (const float*)nullptr,
+                     (const float*)nullptr, 0, 1, mode, gumbel_u, B, temp, alpha, (float*)nullptr, ctx,
+                     (float*)nullptr, (float*)nullptr, 0);
+  DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
 

@@ -318,3 +318,50 @@ class ResNetRunner:
                                 ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
         check(rc, "dic_resnet_fwd")
         return out
+
+
+# ---------------------------------------------------------------------------------------------
+# greedy decode + stand-alone attention
+# ---------------------------------------------------------------------------------------------
+def decoder_greedy(weights: Dict[str, torch.Tensor], feat_rgb: torch.Tensor, feat_depth: Optional[torch.Tensor],
+                   id_start: int, max_length: int = 30, mode: int = 0, gumbel_u: Optional[torch.Tensor] = None):
+    """dic_decoder_greedy. Returns (ids int64 [B,max_length] on device, alphas [B,max_length,196])."""
+    lib = _lib.load()
+    f_rgb = _dev_f32(feat_rgb, "features")
+    f_dep = _dev_f32(feat_depth, "depth_features") if feat_depth is not None else None
+    B = f_rgb.shape[0]
+    vocab = weights["linear.weight"].shape[0]
+    wp, keep = decoder_ptrs(weights)
+    lib.dic_decoder_greedy_workspace_bytes.restype = C.c_size_t
+    need = lib.dic_decoder_greedy_workspace_bytes(B, max_length, vocab)
+    ws = torch.empty(need, dtype=torch.uint8, device=f_rgb.device)
+    ids = torch.empty((B, max_length), dtype=torch.int64, device=f_rgb.device)
+    alphas = torch.empty((B, max_length, L_CELLS), dtype=torch.float32, device=f_rgb.device)
+    gu = _dev_f32(gumbel_u, "gumbel_u") if gumbel_u is not None else None
+    rc = lib.dic_decoder_greedy(C.byref(wp), vocab, ptr(f_rgb), ptr(f_dep), B, C.c_longlong(int(id_start)), max_length,
+                                mode, ptr(gu), ptr(ids), ptr(alphas), ptr(ws), C.c_size_t(ws.numel()), stream_ptr())
+    check(rc, "dic_decoder_greedy")
+    return ids, alphas
+
+
+def attention_forward(att: Dict[str, torch.Tensor], feats: torch.Tensor, h: torch.Tensor, mode: int = 0,
+                      gumbel_u: Optional[torch.Tensor] = None, temp: float = 1.0):
+    """dic_attention_fwd. `att` holds encoder_att/decoder_att/full_att weight+bias. Returns (ctx [B,2048], alpha [B,196])."""
+    lib = _lib.load()
+    f = _dev_f32(feats, "encoder_out")
+    hh = _dev_f32(h, "decoder_hidden")
+    B = f.shape[0]
+    if tuple(f.shape[1:]) != (L_CELLS, D_ENC) or tuple(hh.shape) != (B, D_HID):
+        raise _lib.DicError("attention_forward: expected encoder_out [B,196,2048] and decoder_hidden [B,128]")
+    t = {k: _dev_f32(v, k) for k, v in att.items()}
+    lib.dic_attention_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(lib.dic_attention_workspace_bytes(B), dtype=torch.uint8, device=f.device)
+    ctx = torch.empty((B, D_ENC), dtype=torch.float32, device=f.device)
+    alpha = torch.empty((B, L_CELLS), dtype=torch.float32, device=f.device)
+    gu = _dev_f32(gumbel_u, "gumbel_u") if gumbel_u is not None else None
+    rc = lib.dic_attention_fwd(ptr(t["encoder_att.weight"]), ptr(t["encoder_att.bias"]), ptr(t["decoder_att.weight"]),
+                               ptr(t["decoder_att.bias"]), ptr(t["full_att.weight"]), ptr(t["full_att.bias"]), ptr(f),
+                               ptr(hh), B, mode, ptr(gu), C.c_float(temp), ptr(ctx), ptr(alpha), ptr(ws),
+                               C.c_size_t(ws.numel()), stream_ptr())
+    check(rc, "dic_attention_fwd")
+    return ctx, alpha

@@ -92,6 +92,25 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
                     const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* greedy decoding: batch_sample / sample (depth_models.py:216-305 soft, 698-789 hard with Gumbel-max).
+ *   Starts from id_start (<start>), max_length steps, dropout off, token = argmax(linear(h)); the previous
+ *   token stays on the device (the reference copies it to the host every step, :298-299).
+ *   out_ids: int64 [B,max_length]; alphas_out (nullable when max_length <= 8): [B,max_length,196];
+ *   mode 0 soft | 2 hard (gumbel_u [max_length,B,196]). */
+size_t dic_decoder_greedy_workspace_bytes(int B, int max_length, int V);
+int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth, int B,
+                       long long id_start, int max_length, int mode, const float* gumbel_u, int64_t* out_ids,
+                       float* alphas_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* stand-alone attention module: Soft_Attention.forward (attention.py:81-95), Hard_Attention.forward (:132-148,
+ *   mode 1, gumbel_u [B,196], temp) and Hard_Attention.Hard_sample (:150-167, mode 2): feats [B,196,2048],
+ *   h [B,128] -> ctx [B,2048], alpha [B,196] (float; one-hot in mode 2). Forward only. */
+size_t dic_attention_workspace_bytes(int B);
+int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const float* dec_att_w, const float* dec_att_b,
+                      const float* full_att_w, const float* full_att_b, const float* feats, const float* h, int B,
+                      int mode, const float* gumbel_u, float temp, float* ctx, float* alpha, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- loss of train_Cdepth_soft (depth_train.py:210-216): mean CE over packed tokens
  *      + lam * mean_{B,L}((1 - sum_t alpha)^2).  targets: int64 [n_packed] (device, packed like the
  *      logits).  Writes loss[0] (device), dlogits [n_packed,V] (may alias logits) and, if alphas is

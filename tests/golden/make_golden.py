@@ -269,3 +269,22 @@ if __name__ == "__main__":
     case_adamw3()
     case_batch_sample()
     case_depth_encoder()
+
+
+def case_state_dict_keys():
+    """Key/shape inventory of the reference modules (drop-in boundary)."""
+    import json
+    out = {}
+    for name, mod in (("CD_RNNDecoderWithSoftAttention", CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, 50, 0.5)),
+                      ("CD_RNNDecoderWithHardAttention", CD_RNNDecoderWithHardAttention(128, 128, 2048, 128, 50, "cpu", 0.5)),
+                      ("Depth_CNN_endoder", Depth_CNN_endoder(14)),
+                      ("Soft_Attention", Soft_Attention(2048, 128, 128))):
+        out[name] = {"state_dict": {k: list(v.shape) for k, v in mod.state_dict().items()},
+                     "parameters": [k for k, _ in mod.named_parameters()]}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("state_dict_keys ok")
+
+
+if __name__ == "__main__":
+    case_state_dict_keys()

@@ -1,0 +1,232 @@
+"""GPU: the drop-in nn.Module surface (same call pattern as depth_train.py:179-221) against the oracle and the
+reference's golden vectors - forward values, autograd gradients on .grad, greedy decode token ids."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence
+
+from depth_image_captioning_pub_amd import synthetic as syn
+from depth_image_captioning_pub_amd.Captioning_models.attention import Hard_Attention, Soft_Attention
+from depth_image_captioning_pub_amd.Captioning_models.Base_caption_model.base_caption_models import (
+    CNNEncoder_Atten, RNNDecoderWithSoftAttention)
+from depth_image_captioning_pub_amd.Captioning_models.Depth_caption_model.depth_models import (
+    CD_RNNDecoderWithHardAttention, CD_RNNDecoderWithSoftAttention, Depth_CNN_endoder)
+from oracle import captioning_oracle as orc
+from tests.helpers import check_packed, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(name, got, ref, tol, atol=0.0):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, name
+    scale = float(ref.abs().max()) + 1e-12
+    err = float((got - ref).abs().max())
+    assert np.isfinite(err) and err <= tol * scale + atol, f"{name}: {err:.3e} > {tol:g}*{scale:.3e}+{atol:g}"
+
+
+def test_soft_attention_module_golden(lib):
+    g = load_golden("soft_attention")
+    w = syn.decoder_weights(50, seed=11)
+    att = Soft_Attention(2048, 128, 128)
+    att.load_state_dict({k[len("attention."):]: v for k, v in w.items() if k.startswith("attention.")})
+    att.to(DEV)
+    feats = syn.features(3, 12, replicate=False).to(DEV)
+    h = torch.from_numpy(np.random.Generator(np.random.PCG64(13)).standard_normal((3, 128)).astype(np.float32)).to(DEV)
+    ctx, alpha = att(feats, h)
+    check_packed(g, "ctx", ctx, 1e-4, 1e-5)
+    check_packed(g, "alpha", alpha, 1e-4, 1e-6)
+
+
+def test_hard_attention_module_rng_and_onehot(lib):
+    w = syn.decoder_weights(50, seed=11)
+    att = Hard_Attention(2048, 128, 128)
+    att.load_state_dict({k[len("attention."):]: v for k, v in w.items() if k.startswith("attention.")})
+    att.to(DEV)
+    feats = syn.features(4, 12)
+    h = torch.randn(4, 128, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(77)
+    ctx, alpha = att.Hard_sample(feats.to(DEV), h.to(DEV), DEV)
+    torch.manual_seed(77)
+    u = torch.rand(4, 196)                                   # the reference draws exactly this (attention.py:40)
+    ctx_ref, alpha_ref = orc.hard_attention_sample(w, feats, h, u)
+    assert alpha.dtype == torch.int64 and torch.equal(alpha.cpu(), alpha_ref)
+    _close("ctx", ctx, ctx_ref, 1e-5)
+    torch.manual_seed(78)
+    ctx2, alpha2 = att(feats.to(DEV), h.to(DEV), DEV, torch.tensor(0.7))
+    torch.manual_seed(78)
+    c_ref, a_ref = orc.hard_attention_train(w, feats, h, torch.rand(4, 196), torch.tensor(0.7))
+    _close("alpha", alpha2, a_ref, 1e-4)
+    _close("ctx", ctx2, c_ref, 1e-4)
+
+
+def _decoder_case(lengths, vocab, seed):
+    B = len(lengths)
+    w = syn.decoder_weights(vocab, seed=seed)
+    f_rgb = syn.features(B, seed + 1)
+    f_dep = syn.features(B, seed + 2, scale=0.5)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=seed)
+    return w, f_rgb, f_dep, caps, lens
+
+
+def test_decoder_module_train_step_like_reference_loop(lib):
+    """encoder features -> decoder -> CE + 0.7*reg -> loss.backward() -> AdamW.step(), as depth_train.py:207-221."""
+    lengths, vocab, seed = [9, 7, 7, 4, 3], 50, 21
+    g = load_golden("decoder_soft_ragged_train")
+    w, f_rgb, f_dep, caps, lens = _decoder_case(lengths, vocab, seed)
+    dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    dec.load_state_dict(w)
+    dec.to(DEV).train()
+    drop = syn.dropout_multiplier(len(lens), max(lens) - 1, 0.5, seed=seed).to(DEV)
+    dec._dropout_mult = lambda B, T, dev: drop             # explicit mask (quirk Q6)
+    # strided encoder outputs like the reference's permuted views (quirk Q7)
+    fr = f_rgb.to(DEV).permute(0, 2, 1).contiguous().permute(0, 2, 1).requires_grad_(True)
+    fd = f_dep.to(DEV).requires_grad_(True)
+    assert not fr.is_contiguous()
+    opt = torch.optim.AdamW(dec.parameters(), lr=1e-3)
+    opt.zero_grad()
+    outputs, alphas = dec(fr, fd, caps.to(DEV), lens)
+    assert list(outputs.batch_sizes) == list(g["batch_sizes"])
+    targets = pack_padded_sequence(caps[:, 1:].to(DEV), [l - 1 for l in lens], batch_first=True)
+    loss = F.cross_entropy(outputs.data, targets.data) + 0.7 * ((1.0 - alphas.sum(dim=1)) ** 2).mean()
+    assert abs(float(loss.item()) - float(g["loss"])) <= 1e-4
+    assert np.array_equal(outputs.data.argmax(1).cpu().numpy(), g["argmax"])
+    loss.backward()
+    for k, p in dec.named_parameters():
+        gk = p.grad.cpu()
+        check_packed(g, "grad." + k, gk, 2e-3, 1e-6 if k.endswith("full_att.bias") else 1e-3 * float(gk.abs().max()))
+    check_packed(g, "grad.features", fr.grad.cpu(), 2e-3, 1e-3 * float(fr.grad.abs().max()))
+    check_packed(g, "grad.depth_features", fd.grad.cpu(), 2e-3, 1e-3 * float(fd.grad.abs().max()))
+    opt.step()
+    for k, p in dec.named_parameters():
+        check_packed(g, "adamw1." + k, p.detach().cpu(), 1e-4, 1.5e-3 if k.endswith("full_att.bias") else 2e-5)
+
+
+def test_decoder_module_eval_and_base_variant(lib):
+    lengths, vocab, seed = [9, 7, 7, 4, 3], 50, 21
+    g = load_golden("decoder_soft_ragged_eval")
+    w, f_rgb, f_dep, caps, lens = _decoder_case(lengths, vocab, seed)
+    dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    dec.load_state_dict(w)
+    dec.to(DEV).eval()
+    with torch.no_grad():
+        out, alphas = dec(f_rgb.to(DEV), f_dep.to(DEV), caps.to(DEV), lens)
+    check_packed(g, "logits", out.data, 1e-3, 1e-4)
+    check_packed(g, "alphas", alphas, 1e-3, 1e-5)
+    base = RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    base.load_state_dict(w)
+    base.to(DEV).eval()
+    with torch.no_grad():
+        out_b, _ = base((f_rgb + f_dep).to(DEV), caps.to(DEV), lens)       # base model on the pre-summed features
+    _close("base logits", out_b.data, out.data, 1e-5)
+
+
+def test_hard_decoder_module_reference_rng_order(lib):
+    """With the same torch seed the module consumes the CPU generator exactly like the reference
+    (one torch.rand(bs_valid,196) per step), so results equal the oracle fed with those draws."""
+    lengths, vocab, seed = [9, 7, 7, 4, 3], 50, 23
+    w, f_rgb, f_dep, caps, lens = _decoder_case(lengths, vocab, seed)
+    dec = CD_RNNDecoderWithHardAttention(128, 128, 2048, 128, vocab, DEV, 0.5)
+    dec.load_state_dict(w)
+    dec.to(DEV).eval()
+    dec_len = [l - 1 for l in lens]
+    bsz = orc.batch_sizes_of(dec_len)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = dec(f_rgb.to(DEV), f_dep.to(DEV), caps.to(DEV), lens, torch.tensor(0.8))
+    torch.manual_seed(5)
+    u = torch.full((len(bsz), len(lens), 196), 0.5)
+    for t, nb in enumerate(bsz):
+        u[t, :nb] = torch.rand(nb, 196)
+    ref, _, _ = orc.decoder_forward(w, f_rgb, f_dep, caps, lens, None, hard_u=u, temp=torch.tensor(0.8))
+    _close("hard logits", out.data, ref, 1e-4)
+    torch.manual_seed(6)
+    out2 = dec.eval_forward(f_rgb.to(DEV), f_dep.to(DEV), caps.to(DEV), lens)
+    torch.manual_seed(6)
+    for t, nb in enumerate(bsz):
+        u[t, :nb] = torch.rand(nb, 196)
+    ref2, _, _ = orc.decoder_forward(w, f_rgb, f_dep, caps, lens, None, hard_u=u, hard_eval=True)
+    _close("hard eval logits", out2.data, ref2, 1e-4)
+
+
+def test_batch_sample_and_sample_golden(lib):
+    g = load_golden("batch_sample")
+    vocab = 50
+    w = syn.decoder_weights(vocab, seed=41)
+    dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, vocab, 0.5)
+    dec.load_state_dict(w)
+    dec.to(DEV).eval()
+    f, d = syn.features(4, 42).to(DEV), syn.features(4, 43, scale=0.5).to(DEV)
+    ids = dec.batch_sample(f, d, syn.special_token_ids(vocab), max_length=30)
+    assert ids.dtype == np.int64 and np.array_equal(ids, g["ids"])               # token ids bit-exact
+    preds, alphas = dec.sample(f[:1], d[:1], syn.special_token_ids(vocab), max_length=30)
+    assert preds == list(g["ids"][0]) and len(alphas) == 30 and tuple(alphas[0].shape) == (1, 196)
+    # a less degenerate check against the oracle: larger vocabulary, different seed
+    w2 = syn.decoder_weights(300, seed=91)
+    dec2 = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, 300, 0.5)
+    dec2.load_state_dict(w2)
+    dec2.to(DEV).eval()
+    f2, d2 = syn.features(6, 92), syn.features(6, 93, scale=0.5)
+    ref = orc.batch_sample(w2, f2, d2, syn.special_token_ids(300)["<start>"], 30)
+    got = dec2.batch_sample(f2.to(DEV), d2.to(DEV), syn.special_token_ids(300), 30)
+    assert np.array_equal(got, ref.numpy())
+
+
+def test_depth_encoder_module_autograd(lib):
+    w, st = syn.depth_encoder_weights(seed=51)
+    enc = Depth_CNN_endoder(14)
+    sd = enc.state_dict()
+    alias = {"features.0": "conv1", "features.1": "bn1", "features.4": "conv2", "features.5": "bn2",
+             "features.8": "conv3", "features.9": "bn3"}
+    full = {**w, **st}
+    load = {}
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            load[k] = sd[k]
+            continue
+        base = k
+        for a, b in alias.items():
+            if k.startswith(a + "."):
+                base = b + k[len(a):]
+        load[k] = full[base]
+    enc.load_state_dict(load)
+    enc.to(DEV).train()
+    depth = syn.depth_maps(2, seed=51)
+    d_out = torch.from_numpy(np.random.Generator(np.random.PCG64(58)).standard_normal((2, 196, 2048))
+                             .astype(np.float32)) * 1e-2
+    y = enc(depth.to(DEV))
+    (y * d_out.to(DEV)).sum().backward()
+    gold = load_golden("depth_encoder_train")
+    check_packed(gold, "out49", y.reshape(2, 14, 14, 2048)[:, ::2, ::2].reshape(2, 49, 2048), 1e-3, 1e-4)
+    for k, p in enc.named_parameters():
+        if k.startswith("conv") and k.endswith("bias"):
+            continue
+        gk = p.grad.cpu()
+        check_packed(gold, "grad." + k, gk, 5e-3, 2e-3 * float(gk.abs().max()))
+    for i in (1, 2, 3):
+        check_packed(gold, f"bn{i}.running_mean", getattr(enc, f"bn{i}").running_mean, 1e-3, 1e-5)
+        check_packed(gold, f"bn{i}.running_var", getattr(enc, f"bn{i}").running_var, 1e-3, 1e-5)
+        assert int(getattr(enc, f"bn{i}").num_batches_tracked) == 1
+
+
+def test_rgb_encoder_module_vs_oracle(lib):
+    layers = (1, 1, 1, 1)
+    enc = CNNEncoder_Atten(14, layers=layers)
+    w = syn.resnet152_weights(seed=125, layers=layers)
+    sd = enc.state_dict()
+    sd.update(w)
+    enc.load_state_dict(sd)
+    enc.to(DEV).train()
+    x = syn.rgb_images(2, seed=5, size=96)
+    w_ref = {k: v.clone() for k, v in w.items()}
+    y_ref = orc.resnet152_features(w_ref, x, train_bn=True, layers=layers)
+    y = enc(x.to(DEV))
+    _close("features", y, y_ref, 5e-4)
+    _close("running_mean", enc.state_dict()["backbone.1.running_mean"], w_ref["backbone.1.running_mean"], 1e-4, 1e-6)
+    enc.eval()
+    y2 = enc(x.to(DEV))
+    y2_ref = orc.resnet152_features(w_ref, x, train_bn=False, layers=layers)
+    _close("features eval", y2, y2_ref, 5e-4)
