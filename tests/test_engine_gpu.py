@@ -50,12 +50,12 @@ def test_three_fused_steps_vs_oracle(lib):
         assert torch.equal(tr.last["logits"].argmax(1).cpu(), packed_ref.argmax(1))
     # AdamW divides by sqrt(v)+1e-8: wherever |grad| is at the fp32-noise level (exactly-zero-gradient tensors of
     # quirk Q10, and isolated elements with |g| ~ 1e-8) the update DIRECTION is summation-order noise, bounded by lr
-    # per step.  So: hard bound 3*lr (+slack) on every element, tight tolerance on >= 98 % of them (the reference-own 3-step golden, test_decoder_adamw3_golden, is tight on all).
+    # per step.  So: hard bound 3 steps x 2 lr (opposite signs on the two sides) on every element, tight tolerance on >= 98 % of them (the reference-own 3-step golden, test_decoder_adamw3_golden, is tight on all).
     noisy = ("attention.full_att.bias", "conv1.bias", "conv2.bias", "conv3.bias")
     def check_weights(name, got, ref):
         got, ref = got.detach().cpu().double(), ref.double()
         err = (got - ref).abs()
-        assert float(err.max()) <= 3.5e-3, f"{name}: {float(err.max()):.3e} exceeds 3 steps x lr"
+        assert float(err.max()) <= 6.5e-3, f"{name}: {float(err.max()):.3e} exceeds 3 steps x 2 lr"
         if name.split(".", 1)[1] in noisy:
             return
         tight = 2e-4 * float(ref.abs().max()) + 2e-5
