@@ -62,6 +62,35 @@ class FlatParams:
         return lo, min(hi, self.total)
 
 
+def shard_rows(n_rows: int, world: int, rank: int) -> slice:
+    """Rows [r*B/N, (r+1)*B/N) of the (length-sorted) global batch belong to rank r."""
+    if n_rows % world != 0:
+        raise DicError(f"global batch {n_rows} is not divisible by world size {world}")
+    per = n_rows // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def exchange_gradients(flat_grad: torch.Tensor, spans, group, between=None) -> None:
+    """Sum-all-reduce the gradient buckets `spans` = [(lo, hi), ...] of the flat buffer over `group`
+    (RCCL over xGMI on the GPUs; gloo in the CPU tests).  The first bucket is launched asynchronously,
+    then `between()` runs (the depth-encoder backward, which produces the second bucket and overlaps the
+    first collective), then the remaining buckets go out; returns when all have completed on the current
+    stream.  Gradients are expected pre-scaled by 1/world_size, so the sum is the DDP average."""
+    work = []
+    first = True
+    for lo, hi in spans:
+        if not first and between is not None:
+            between()
+            between = None
+        work.append(torch.distributed.all_reduce(flat_grad[lo:hi], op=torch.distributed.ReduceOp.SUM, group=group,
+                                                 async_op=True))
+        first = False
+    if between is not None:
+        between()
+    for w in work:
+        w.wait()
+
+
 class CaptionTrainer:
     """Owns weights, optimiser state and workspaces of one rank and runs fused train steps."""
 
@@ -162,16 +191,11 @@ class CaptionTrainer:
         self._mark("loss")
         _, dfeat = native.decoder_backward(tape, dlogits, dalphas, grads=self.dec_g)         # :219
         self._mark("decoder_bwd")
-        work = []
         if self.world > 1:   # decoder bucket goes out while the depth-encoder backward still runs
-            lo, hi = self.dec_span
-            work.append(torch.distributed.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
-        native.depth_encoder_backward(dtape, dfeat, grads=self.enc_g)
-        if self.world > 1:
-            lo, hi = self.enc_span
-            work.append(torch.distributed.all_reduce(self.flat.grad[lo:hi], group=self.pg, async_op=True))
-            for w in work:
-                w.wait()
+            exchange_gradients(self.flat.grad, [self.dec_span, self.enc_span], self.pg,
+                               between=lambda: native.depth_encoder_backward(dtape, dfeat, grads=self.enc_g))
+        else:
+            native.depth_encoder_backward(dtape, dfeat, grads=self.enc_g)
         self._mark("depth_encoder_bwd+allreduce")
         self.step_count += 1
         native.adamw_step(self.flat.data, self.flat.grad, self.flat.exp_avg, self.flat.exp_avg_sq, self.step_count,
