@@ -19,6 +19,8 @@ int dic_gemm_f32(int M, int N, int K, const float* A, long long lda, int a_colk,
   p.ep = ep_store(C, ldc, bias, act);
   p.ep.accumulate = accumulate;
   p.splitk = splitk; p.ws = workspace;
+  p.ablate = force_tile / 1000;            // benchmark-only ablation switch (scripts/bench_gemm.py)
+  force_tile %= 1000;
   DIC_REQUIRE(force_tile == 0 || force_tile == 64 || force_tile == 128, "force_tile must be 0, 64 or 128");
   if (splitk > 1)
     DIC_REQUIRE(workspace_bytes >= gemm_splitk_ws_bytes(M, N, splitk), "dic_gemm_f32: workspace too small");
@@ -32,6 +34,7 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
   return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile);
 }
 
+int dic_debug_force_staged_gemm(int on) { gemm_force_v1(on); return 0; }
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
   DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");

@@ -42,6 +42,7 @@ constexpr int kWg2Split = 4;
 
 struct DepthWs {
   float *w2o, *x1, *y1p, *x2, *y2p, *x3, *partial;
+  double* red;
   unsigned char *idx1, *idx2;
   BnBuf bn1, bn2, bn3;
   // backward
@@ -71,6 +72,8 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   part = std::max(part, (size_t)(g.M2 / 64 + 2) * 2 * 512);
   part = std::max(part, (size_t)(g.M3 / 64 + 2) * 2 * 2048);
   w.partial = c.take<float>(part);
+  w.red = c.take<double>(std::max(std::max(bn_finalize_ws_doubles(g.M1 / 64 + 2, 128), bn_finalize_ws_doubles(g.M2 / 64 + 2, 512)),
+                                   bn_finalize_ws_doubles(g.M3 / 64 + 2, 2048)));
   w.bn1 = take_bn(c, 128); w.bn2 = take_bn(c, 512); w.bn3 = take_bn(c, 2048);
   w.dy1 = c.take<float>((size_t)g.M1 * 128);
   w.dy1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
@@ -98,13 +101,14 @@ struct RnConv {
 
 struct RnPlan {
   std::vector<RnConv> convs;       // execution order == layer order
-  size_t max_act = 0, max_partial = 0;
+  size_t max_act = 0, max_partial = 0, max_red = 0;
   int outH = 0, outW = 0;
 };
 
 static void rn_track(RnPlan& pl, const ConvDesc& d) {
   pl.max_act = std::max(pl.max_act, (size_t)d.M() * d.CO);
   pl.max_partial = std::max(pl.max_partial, (size_t)(d.M() / 64 + 2) * 2 * d.CO);
+  pl.max_red = std::max(pl.max_red, bn_finalize_ws_doubles(d.M() / 64 + 2, d.CO));
 }
 
 static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
@@ -142,6 +146,7 @@ static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
 struct RnWs {
   float* act[4];
   float* partial;
+  double* red;
   BnBuf bn;
   size_t bytes;
 };
@@ -151,6 +156,7 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, bool* ov) {
   RnWs w{};
   for (int i = 0; i < 4; ++i) w.act[i] = c.take<float>(pl.max_act);
   w.partial = c.take<float>(pl.max_partial);
+  w.red = c.take<double>(pl.max_red);
   w.bn = take_bn(c, 2048);
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
@@ -159,11 +165,11 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, bool* ov) {
 
 // conv -> (train: batch statistics from the epilogue partials | eval: running stats) -> scale/shift in bn
 static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L, float* y, float* partial, BnBuf bn,
-                   int train_bn, hipStream_t st) {
+                   double* red, int train_bn, hipStream_t st) {
   int mtiles = 0;
   DIC_TRY(conv_fwd(x, d, L.w, nullptr, y, train_bn ? partial : nullptr, &mtiles, st));
   if (train_bn)
-    return bn_finalize_train(partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+    return bn_finalize_train(partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, red, st);
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
@@ -199,17 +205,17 @@ int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn
   DIC_TRY(oihw_to_ohwi(w->conv2_w, ws.w2o, 512, 128, 3, 3, st));
   // conv1 (1->128, k7 s3) + BN + ReLU + maxpool3          (depth_models.py:19-20,36-39)
   DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
-  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
+  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, ws.red, st));
   else DIC_TRY(bn_finalize_eval(128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
   DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st));
   // conv2 (128->512, k3) + BN + ReLU + maxpool3            (:21-22,40-43)
   DIC_TRY(conv_fwd(ws.y1p, g.c2, ws.w2o, w->conv2_b, ws.x2, train ? ws.partial : nullptr, &mt, st));
-  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M2, 512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
+  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M2, 512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, ws.red, st));
   else DIC_TRY(bn_finalize_eval(512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
   DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st));
   // conv3 (512->2048, k1) + BN + ReLU + AdaptiveAvgPool(14) -> [B,196,2048]   (:23-24,44-47,54)
   DIC_TRY(conv_fwd(ws.y2p, g.c3, w->conv3_w, w->conv3_b, ws.x3, train ? ws.partial : nullptr, &mt, st));
-  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
+  if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, ws.red, st));
   else DIC_TRY(bn_finalize_eval(2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
   DIC_TRY(adaptive_avgpool(ws.x3, B, g.P2h, g.P2w, 2048, &ws.bn3, 1, 14, features, st));
   return DIC_OK;
@@ -277,7 +283,7 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
   // stem: conv7x7 s2 + BN + ReLU + maxpool 3x3 s2 p1
   {
     const RnConv& c = pl.convs[ci++];
-    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, train_bn, st));
+    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, train_bn, st));
     DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
   }
   for (int s = 0; s < 4; ++s)
@@ -285,18 +291,18 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
       const RnConv& c1 = pl.convs[ci++];
       const RnConv& c2 = pl.convs[ci++];
       const RnConv& c3 = pl.convs[ci++];
-      DIC_TRY(conv_bn(X, c1.d, layers[c1.layer], A, ws.partial, ws.bn, train_bn, st));
+      DIC_TRY(conv_bn(X, c1.d, layers[c1.layer], A, ws.partial, ws.bn, ws.red, train_bn, st));
       DIC_TRY(bn_apply(A, nullptr, A, c1.d.M(), c1.d.CO, ws.bn, 1, st));
-      DIC_TRY(conv_bn(A, c2.d, layers[c2.layer], Bf, ws.partial, ws.bn, train_bn, st));
+      DIC_TRY(conv_bn(A, c2.d, layers[c2.layer], Bf, ws.partial, ws.bn, ws.red, train_bn, st));
       DIC_TRY(bn_apply(Bf, nullptr, Bf, c2.d.M(), c2.d.CO, ws.bn, 1, st));
       const float* identity = X;
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
-        DIC_TRY(conv_bn(X, ds.d, layers[ds.layer], Cf, ws.partial, ws.bn, train_bn, st));
+        DIC_TRY(conv_bn(X, ds.d, layers[ds.layer], Cf, ws.partial, ws.bn, ws.red, train_bn, st));
         DIC_TRY(bn_apply(Cf, nullptr, Cf, ds.d.M(), ds.d.CO, ws.bn, 0, st));
         identity = Cf;
       }
-      DIC_TRY(conv_bn(Bf, c3.d, layers[c3.layer], A, ws.partial, ws.bn, train_bn, st));
+      DIC_TRY(conv_bn(Bf, c3.d, layers[c3.layer], A, ws.partial, ws.bn, ws.red, train_bn, st));
       DIC_TRY(bn_apply(A, identity, Bf, c3.d.M(), c3.d.CO, ws.bn, 1, st));      // out = relu(bn3 + identity)
       std::swap(X, Bf);
     }

@@ -58,6 +58,7 @@ struct GemmParams {
   int splitk;           // >1: raw partials go to ws[z][M][N]; splitk_reduce applies the epilogue
   int ktiles_per_split;
   float* ws;
+  int ablate;           // debug/benchmark only: 1 no global traffic in the loop, 2 also no LDS reads, 3 LDS stores but no global loads
   int raw_partials;     // split-K: leave the [splitk][M][N] partial slabs in ws, skip the reduce launch
 };
 
@@ -71,6 +72,7 @@ GemmOperand op_im2col(const float* x, const ConvGeom& g);
 GemmOperand op_gather(const float* x, const ConvGeom& g);
 GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
 GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
+void gemm_force_v1(int on);
 int gemm_profile_begin();
 int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
 GemmEpilogue ep_store(float* C, long long ldc, const float* bias = nullptr, int act = ACT_NONE);

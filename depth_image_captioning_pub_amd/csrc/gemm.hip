@@ -213,7 +213,216 @@ __device__ __forceinline__ float finalize_store(const GemmEpilogue& ep, int m, i
   return v;
 }
 
-template <int BM, int BN, int AK, int BKIND>
+// ------------------------------------------------------------------------------------------
+// shared epilogue: C/D map of the 32x32 MFMA is col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// `sb` is LDS scratch (>= 2*BN floats) that is free once the main loop has ended on a barrier.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], int tm, int tn,
+                                              int z, float* sb) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, khalf = lane >> 5;
+  const int n0 = tn * BN + wn * WN + (lane & 31);
+  const int m0 = tm * BM + wm * WM + 4 * khalf;
+  float cs[TN], cs2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cs2[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + j * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (m < p.M && n < p.N) {
+          if (p.splitk > 1) {
+            p.ws[((long long)z * p.M + m) * p.N + n] = acc[i][j][r];
+          } else {
+            const float v = finalize_store(p.ep, m, n, acc[i][j][r]);
+            cs[j] += v;
+            cs2[j] += v * v;
+          }
+        }
+      }
+    }
+  if (p.ep.stats && p.splitk == 1) {   // per-(m-tile, column) partial sums for train-mode BatchNorm
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      cs[j] += __shfl_xor(cs[j], 32, 64);
+      cs2[j] += __shfl_xor(cs2[j], 32, 64);
+    }
+    if (wm == 0 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        sb[wn * WN + j * 32 + lane] = cs[j];
+        sb[BN + wn * WN + j * 32 + lane] = cs2[j];
+      }
+    }
+    __syncthreads();
+    if (wm == 1 && lane < 32) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 32;
+        if (n < p.N) {
+          p.ep.stats[((long long)tm * 2 + 0) * p.N + n] = cs[j] + sb[wn * WN + j * 32 + lane];
+          p.ep.stats[((long long)tm * 2 + 1) * p.N + n] = cs2[j] + sb[BN + wn * WN + j * 32 + lane];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// v2: both operands K-contiguous (linear layers, implicit-GEMM convolutions with C % 32 == 0).
+// Tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write): one wave
+// instruction fills 8 rows x 128 B of a row-major [rows][32] image.  The DMA destination is lane-linear,
+// so the bank-conflict swizzle lives on the SOURCE side: 16-B position p of row r receives data chunk
+// p ^ ((r>>1)&7); fragments are ds_read_b128 of chunk c at position c ^ ((r>>1)&7) (conflict-free for the
+// 16-lane groups of ds_read_b128).  One 16-B read yields 4 k-steps; lane half h takes chunk 2g+h, i.e. the
+// MFMA k index is permuted identically for A and B (k = 8g + 4h + s), which leaves the sum unchanged.
+// Out-of-range rows / K tail / convolution padding read a zero line instead of being predicated.
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) const float g_zero_line[64] = {0.f};
+
+template <int KIND, int BR>
+struct DmaLoader {
+  static constexpr int NI = BR / 32;          // wave-instructions per wave and K tile
+  const float* p;
+  int K;
+  ConvGeom g;
+  const float* rowptr[NI];
+  bool valid[NI];
+  int ih0[NI], iw0[NI];
+  int chunk[NI];                              // pre-swizzled source chunk of this lane
+
+  __device__ __forceinline__ void init(const GemmOperand& op, int r0, int R, int K_) {
+    p = op.p; K = K_; g = op.g;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int row = (n * 4 + w) * 8 + (lane >> 3);
+      const int gr = r0 + row;
+      valid[n] = gr < R;
+      chunk[n] = (lane & 7) ^ ((row >> 1) & 7);
+      if constexpr (KIND == OPK_ROWK) {
+        rowptr[n] = p + (long long)gr * op.ld;
+      } else {
+        const int ohw = g.OH * g.OW;
+        const int img = gr / ohw, rem = gr - img * ohw;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        ih0[n] = oh * g.stride - g.pad;
+        iw0[n] = ow * g.stride - g.pad;
+        rowptr[n] = p + (long long)img * g.H * g.W * g.C;
+      }
+    }
+  }
+
+  // issue the DMA of K tile k0 into `img` (this operand's [BR][32] image of one stage)
+  __device__ __forceinline__ void issue(int k0, float* img) const {
+    const int w = threadIdx.x >> 6;
+    int kh = 0, kw = 0, c0 = 0;
+    if constexpr (KIND == OPK_IM2COL) {
+      const int kpos = k0 / g.C;
+      c0 = k0 - kpos * g.C;
+      kh = kpos / g.KW;
+      kw = kpos - kh * g.KW;
+    }
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const float* src = g_zero_line;
+      if constexpr (KIND == OPK_ROWK) {
+        const int k = k0 + chunk[n] * 4;
+        if (valid[n] && k < K) src = rowptr[n] + k;
+      } else {
+        const int ih = ih0[n] + kh, iw = iw0[n] + kw;
+        if (valid[n] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+          src = rowptr[n] + ((long long)ih * g.W + iw) * g.C + c0 + chunk[n] * 4;
+      }
+      float* dst = img + ((n * 4 + w) * 8) * BK;            // wave-uniform 1-KiB block
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
+};
+
+template <int BM, int BN, int AK>
+__global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int STAGE = (BM + BN) * BK;                        // floats per pipeline stage
+  __shared__ __align__(1024) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.mtiles * p.ntiles;
+  const int z = lb / tiles, t = lb - z * tiles;
+  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+
+  DmaLoader<AK, BM> la;
+  DmaLoader<OPK_ROWK, BN> lbld;
+  la.init(p.A, tm * BM, p.M, p.K);
+  lbld.init(p.B, tn * BN, p.N, p.K);
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int kt0 = z * p.ktiles_per_split;
+  const int kt1 = min(nk, kt0 + p.ktiles_per_split);
+  const int nkt = kt1 - kt0;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    la.issue(kt0 * BK, smem);
+    lbld.issue(kt0 * BK, smem + BM * BK);
+  }
+  __syncthreads();          // (vmcnt(0) + barrier: hipcc drains the LDS-DMA before the barrier)
+
+  // fragment addressing: row = wave offset + 32*t + (lane&31); swizzle key (row>>1)&7 depends on the lane only
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 1) & 7;
+  int pos[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) pos[gq] = ((2 * gq + h) ^ key) * 4;
+  const int aoff = (wm * WM + i31) * BK, boff = BM * BK + (wn * WN + i31) * BK;
+
+  for (int it = 0; it < nkt; ++it) {
+    const float* st = smem + (it & 1) * STAGE;
+    if (it + 1 < nkt) {
+      float* nx = smem + ((it + 1) & 1) * STAGE;
+      la.issue((kt0 + it + 1) * BK, nx);
+      lbld.issue((kt0 + it + 1) * BK, nx + BM * BK);
+    }
+    float4 af[TM][4], bf[TN][4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][gq] = *reinterpret_cast<const float4*>(st + aoff + i * 32 * BK + pos[gq]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j][gq] = *reinterpret_cast<const float4*>(st + boff + j * 32 * BK + pos[gq]);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][gq].x, bf[j][gq].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][gq].y, bf[j][gq].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][gq].z, bf[j][gq].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][gq].w, bf[j][gq].w, acc[i][j], 0, 0, 0);
+        }
+    __syncthreads();
+  }
+  gemm_epilogue<BM, BN>(p, acc, tm, tn, z, smem);
+}
+
+template <int BM, int BN, int AK, int BKIND, int ABL = 0>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   using LA = Loader<AK, BM>;
   using LB = Loader<BKIND, BN>;
@@ -246,99 +455,62 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Register-staged pipeline, two tiles deep: at iteration `it` the registers hold tile it+1 (loaded one
+  // iteration ago, so its latency is covered by a whole tile of MFMAs); it is written to the free LDS
+  // buffer at the top of the iteration, the loads for tile it+2 are issued, and only then the MFMAs of
+  // tile `it` run.  All fragments of a K tile are read from LDS up front (one wait ladder instead of a
+  // read->wait->MFMA round trip per k-step).
   float4 ra[LA::NV], rb[LB::NV];
-  if (kt0 < kt1) {
+  const int nkt = kt1 - kt0;
+  if (nkt > 0) {
     la.load(kt0 * BK, ra);
     lbld.load(kt0 * BK, rb);
     la.store(As[0], ra);
     lbld.store(Bs[0], rb);
+  }
+  if (nkt > 1) {
+    la.load((kt0 + 1) * BK, ra);
+    lbld.load((kt0 + 1) * BK, rb);
   }
   __syncthreads();
 
   const int arow = wm * WM + (lane & 31);
   const int brow = wn * WN + (lane & 31);
   const int khalf = lane >> 5;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    if (more) {
-      la.load((kt + 1) * BK, ra);
-      lbld.load((kt + 1) * BK, rb);
+  for (int it = 0; it < nkt; ++it) {
+    const int cur = it & 1;
+    if (ABL == 0 || ABL == 3) {
+    if (it + 1 < nkt) {
+      la.store(As[cur ^ 1], ra);
+      lbld.store(Bs[cur ^ 1], rb);
     }
-    const float* Ac = As[cur];
-    const float* Bc = Bs[cur];
+    if (it + 2 < nkt && ABL == 0) {
+      la.load((kt0 + it + 2) * BK, ra);
+      lbld.load((kt0 + it + 2) * BK, rb);
+    }
+    }
+    const float* Ac = As[cur] + khalf * LDA + arow;
+    const float* Bc = Bs[cur] + khalf * LDB + brow;
+    float af[TM][BK / 2], bf[TN][BK / 2];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int krow = kk * 2 + khalf;
-      float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ac[krow * LDA + arow + i * 32];
+      for (int i = 0; i < TM; ++i) af[i][kk] = (ABL == 2) ? (float)(it + kk + i) : Ac[kk * 2 * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bc[krow * LDB + brow + j * 32];
+      for (int j = 0; j < TN; ++j) bf[j][kk] = (ABL == 2) ? (float)(it - kk + j) : Bc[kk * 2 * LDB + j * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      la.store(As[cur ^ 1], ra);
-      lbld.store(Bs[cur ^ 1], rb);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int n0 = tn * BN + wn * WN + (lane & 31);
-  const int m0 = tm * BM + wm * WM + 4 * khalf;
-  float cs[TN], cs2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { cs[j] = 0.f; cs2[j] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + j * 32;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2);
-        if (m < p.M && n < p.N) {
-          if (p.splitk > 1) {
-            p.ws[((long long)z * p.M + m) * p.N + n] = acc[i][j][r];
-          } else {
-            const float v = finalize_store(p.ep, m, n, acc[i][j][r]);
-            cs[j] += v;
-            cs2[j] += v * v;
-          }
-        }
-      }
-    }
-  if (p.ep.stats && p.splitk == 1) {   // per-(m-tile, column) partial sums for train-mode BatchNorm
-    float* sb = As[0];                 // safe: main loop ended on a barrier
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      cs[j] += __shfl_xor(cs[j], 32, 64);
-      cs2[j] += __shfl_xor(cs2[j], 32, 64);
-    }
-    if (wm == 0 && lane < 32) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        sb[wn * WN + j * 32 + lane] = cs[j];
-        sb[BN + wn * WN + j * 32 + lane] = cs2[j];
-      }
-    }
-    __syncthreads();
-    if (wm == 1 && lane < 32) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + j * 32;
-        if (n < p.N) {
-          p.ep.stats[((long long)tm * 2 + 0) * p.N + n] = cs[j] + sb[wn * WN + j * 32 + lane];
-          p.ep.stats[((long long)tm * 2 + 1) * p.N + n] = cs2[j] + sb[BN + wn * WN + j * 32 + lane];
-        }
-      }
-    }
-  }
+  gemm_epilogue<BM, BN>(p, acc, tm, tn, z, As[0]);
 }
 
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) {
@@ -358,6 +530,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
 // every contraction launch, summed per kernel instantiation (tile, A kind, B kind).
 struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
 static bool g_prof_on = false;
+static bool g_force_v1 = false;   // benchmarking switch: register-staged kernel for every shape
+void gemm_force_v1(int on) { g_force_v1 = on != 0; }
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 
@@ -440,8 +614,10 @@ size_t gemm_splitk_ws_bytes(int M, int N, int splitk) {
 }
 
 int gemm_pick_tile(int M, int N) {
+  // Measured on MI355X (scripts/bench_gemm.py): the 64x64 tile (4 workgroups/CU) matches or beats 128x128 on
+  // every shape of the path up to 4096^3; the big tile only pays once the grid is many rounds deep.
   const long long t128 = (long long)ceil_div(M, 128) * ceil_div(N, 128);
-  if (N >= 128 && t128 >= 384) return 128;
+  if (N >= 128 && M >= 128 && t128 >= 4096) return 128;
   return 64;
 }
 
@@ -453,6 +629,12 @@ static int launch_tile(const GemmParams& p, hipStream_t st) {
   if (a == AK_ && b == BK_) {                                                       \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AK_, BK_>), grid, block, 0, st, p);     \
     return DIC_OK;                                                                  \
+  }
+  if (a == OPK_ROWK && b == OPK_ROWK && p.ablate > 0) {
+    if (p.ablate == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, OPK_ROWK, OPK_ROWK, 1>), grid, block, 0, st, p);
+    else if (p.ablate == 2) hipLaunchKernelGGL((gemm_kernel<BM, BN, OPK_ROWK, OPK_ROWK, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, OPK_ROWK, OPK_ROWK, 3>), grid, block, 0, st, p);
+    return DIC_OK;
   }
   DIC_GEMM_CASE(OPK_ROWK, OPK_ROWK)
   DIC_GEMM_CASE(OPK_ROWK, OPK_COLK)
@@ -485,6 +667,8 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     DIC_REQUIRE(p.ep.stats == nullptr, "gemm: BN statistics epilogue cannot be combined with split-K");
   }
   if (p.ep.alpha == 0.0f) p.ep.alpha = 1.0f;
+  const bool dma_ok = (p.B.kind == OPK_ROWK && p.B.vec && (p.K % 4 == 0) && p.ablate == 0 && !g_force_v1 &&
+                       (p.A.kind == OPK_IM2COL || (p.A.kind == OPK_ROWK && p.A.vec)));
   ProfRec rec{};
   if (g_prof_on) {
     rec.e0 = prof_event(); rec.e1 = prof_event();
@@ -492,7 +676,19 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     rec.key = (tile == 128 ? 100 : 0) + p.A.kind * 10 + p.B.kind;
     (void)hipEventRecord(rec.e0, st);
   }
-  int rc = (tile == 128) ? launch_tile<128, 128>(p, st) : launch_tile<64, 64>(p, st);
+  int rc = DIC_OK;
+  if (dma_ok) {
+    const dim3 grid(p.mtiles * p.ntiles * p.splitk), block(256);
+    if (tile == 128) {
+      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_IM2COL>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_ROWK>), grid, block, 0, st, p);
+    } else {
+      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_IM2COL>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_ROWK>), grid, block, 0, st, p);
+    }
+  } else {
+    rc = (tile == 128) ? launch_tile<128, 128>(p, st) : launch_tile<64, 64>(p, st);
+  }
   if (rc != 0) return rc;
   DIC_LAUNCH_CHECK();
   if (g_prof_on) {

@@ -14,8 +14,11 @@ struct BnBuf {
 
 // train mode: reduce the conv epilogue's per-tile partial sums [mtiles][2][C] (fp64), produce
 // scale/shift (+ saved mean/invstd) and update the running statistics (unbiased variance).
+// `red`: fp64 scratch of bn_finalize_ws_doubles(max mtiles, C) doubles.
+size_t bn_finalize_ws_doubles(long long max_mtiles, int C);
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma,
-                      const float* beta, float* running_mean, float* running_var, BnBuf out, hipStream_t st);
+                      const float* beta, float* running_mean, float* running_var, BnBuf out, double* red,
+                      hipStream_t st);
 // eval mode: scale/shift from the running statistics
 int bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, BnBuf out, hipStream_t st);

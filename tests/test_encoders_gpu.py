@@ -109,14 +109,21 @@ def test_resnet_small_stacks(lib, layers, B, size, train):
 
 
 def test_resnet152_full_depth(lib):
-    """All 155 conv+BN layers at 224x224 (B=2), batch-statistics mode (quirk Q1)."""
+    """All 155 conv+BN layers at 224x224 (B=2), batch-statistics mode (quirk Q1).  fp32 rounding is amplified by
+    152 layers of batch-statistics BatchNorm over a 2-image batch, so the yardstick is an fp64 evaluation of the
+    oracle: the GPU result must sit inside the same error envelope as the fp32 CPU path (<= 4x its error)."""
     w = syn.resnet152_weights(seed=125)
     x = syn.rgb_images(2, seed=123)
-    torch.set_num_threads(max(1, torch.get_num_threads()))
     y_ref = orc.resnet152_features({k: v.clone() for k, v in w.items()}, x, train_bn=True)
+    y64 = orc.resnet152_features({k: v.double() for k, v in w.items()}, x.double(), train_bn=True)
     runner = native.ResNetRunner(_dev(w))
     y = runner.forward(x.to(DEV), train_bn=True)
     assert y.shape == (2, 196, 2048)
     y4 = y.reshape(2, 7, 2, 7, 2, 2048)
     assert torch.equal(y4[:, :, 0, :, 0], y4[:, :, 1, :, 1]), "7x7 -> 14x14 must be exact 2x2 replication (Q3)"
-    _close("features", y, y_ref, 2e-3)
+    scale = float(y64.abs().max())
+    err_cpu32 = float((y_ref.double() - y64).abs().max()) / scale
+    err_gpu = float((y.cpu().double() - y64).abs().max()) / scale
+    print(f"ResNet-152 fp32 error vs fp64: CPU oracle {err_cpu32:.2e}, HIP {err_gpu:.2e}")
+    assert err_gpu <= max(4.0 * err_cpu32, 5e-4), (err_gpu, err_cpu32)
+    _close("features", y, y_ref, 5e-3)
