@@ -7,7 +7,10 @@
 One "step" = one full training iteration of depth_train.py:168-221 on one batch of synthetic inputs that are
 already resident in HBM: ResNet-152 forward (batch-statistics BN, quirk Q1) -> depth encoder forward ->
 decoder forward (T=20) -> CE + attention regulariser -> BPTT backward -> depth-encoder backward ->
-gradient all-reduce (N>1) -> AdamW.  Nothing is skipped inside the timed region.  Weak scaling: every rank
+gradient all-reduce (N>1) -> AdamW.  Nothing is skipped inside the timed region.  The frozen ResNet forward of
+batch i+1 runs on a side HIP stream concurrently with the rest of step i (it takes no gradient and is not touched
+by the optimiser, so this is pure software pipelining: K timed steps still contain K ResNet forwards and the
+closing synchronize waits for both streams; --no-overlap disables it).  Weak scaling: every rank
 processes --batch images per step (default 64 = BASELINE.json configs[1]); value = N*batch*K / max-rank time.
 
 The JSON line also carries
@@ -103,6 +106,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="do not overlap the next batch's frozen ResNet forward with the current step")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
@@ -138,6 +143,7 @@ def main():
     caps, lens = syn.captions_fixed(B, VOCAB, SEQ_LEN, seed=123 + rank)
     caps = caps.to(dev)
     step_args = (imgs, depth, caps, lens)
+    pipe = {} if args.no_overlap else {"next_imgs": imgs}   # software-pipeline the frozen ResNet across steps
 
     def sync():
         if world > 1:
@@ -146,11 +152,11 @@ def main():
 
     loss = None
     for _ in range(args.warmup):
-        loss = trainer.train_step(*step_args)
+        loss = trainer.train_step(*step_args, **pipe)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.train_step(*step_args)
+        loss = trainer.train_step(*step_args, **pipe)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

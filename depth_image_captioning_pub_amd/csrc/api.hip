@@ -29,9 +29,9 @@ int dic_gemm_f32(int M, int N, int K, const float* A, long long lda, int a_colk,
 
 int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_ohwi, const float* bias,
                    int CO, int KH, int KW, int stride, int pad, float* y_nhwc, float* bn_partial, int* mtiles_out,
-                   int force_tile, void* stream) {
+                   int force_tile, float* tail_ws, void* stream) {
   ConvDesc d{B, H, W, C, CO, KH, KW, stride, pad, in_nchw};
-  return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile);
+  return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile, tail_ws);
 }
 
 int dic_debug_force_staged_gemm(int on) { gemm_force_v1(on); return 0; }

@@ -16,8 +16,9 @@ struct ConvDesc {
 };
 
 // y[B,OH,OW,CO] = conv(x, w) (+bias).  bn_partial (nullable): [mtiles][2][CO] column partials.
+// tail_ws (nullable): kGemmTailWsBytes of scratch enabling the remainder-tile K split (see gemm.hip).
 int conv_fwd(const float* x, const ConvDesc& d, const float* w_ohwi, const float* bias, float* y,
-             float* bn_partial, int* mtiles_out, hipStream_t st, int force_tile = 0);
+             float* bn_partial, int* mtiles_out, hipStream_t st, int force_tile = 0, float* tail_ws = nullptr);
 int conv_mtiles(const ConvDesc& d, int force_tile = 0);
 
 // dW[CO][KH][KW][C] = sum_m dY[m,co] * patch(m)[kh,kw,c]   (split over M with workspace `ws`)

@@ -8,7 +8,7 @@ int conv_mtiles(const ConvDesc& d, int force_tile) {
 }
 
 int conv_fwd(const float* x, const ConvDesc& d, const float* w, const float* bias, float* y, float* bn_partial,
-             int* mtiles_out, hipStream_t st, int force_tile) {
+             int* mtiles_out, hipStream_t st, int force_tile, float* tail_ws) {
   DIC_REQUIRE(d.OH() > 0 && d.OW() > 0, "conv: empty output");
   GemmParams p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -18,6 +18,7 @@ int conv_fwd(const float* x, const ConvDesc& d, const float* w, const float* bia
   p.ep = ep_store(y, d.CO, bias, ACT_NONE);
   p.ep.stats = bn_partial;
   p.splitk = 1;
+  p.tail_ws = tail_ws;
   const int tile = force_tile ? force_tile : gemm_pick_tile(p.M, p.N);
   if (mtiles_out) *mtiles_out = ceil_div(p.M, tile);
   return gemm_launch(p, st, tile);

@@ -146,6 +146,7 @@ static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
 struct RnWs {
   float* act[4];
   float* partial;
+  float* tail;
   double* red;
   BnBuf bn;
   size_t bytes;
@@ -157,6 +158,7 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, bool* ov) {
   for (int i = 0; i < 4; ++i) w.act[i] = c.take<float>(pl.max_act);
   w.partial = c.take<float>(pl.max_partial);
   w.red = c.take<double>(pl.max_red);
+  w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
   w.bn = take_bn(c, 2048);
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
@@ -165,9 +167,9 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, bool* ov) {
 
 // conv -> (train: batch statistics from the epilogue partials | eval: running stats) -> scale/shift in bn
 static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L, float* y, float* partial, BnBuf bn,
-                   double* red, int train_bn, hipStream_t st) {
+                   double* red, float* tail, int train_bn, hipStream_t st) {
   int mtiles = 0;
-  DIC_TRY(conv_fwd(x, d, L.w, nullptr, y, train_bn ? partial : nullptr, &mtiles, st));
+  DIC_TRY(conv_fwd(x, d, L.w, nullptr, y, train_bn ? partial : nullptr, &mtiles, st, 0, tail));
   if (train_bn)
     return bn_finalize_train(partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, red, st);
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
@@ -283,7 +285,7 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
   // stem: conv7x7 s2 + BN + ReLU + maxpool 3x3 s2 p1
   {
     const RnConv& c = pl.convs[ci++];
-    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, train_bn, st));
+    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
     DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
   }
   for (int s = 0; s < 4; ++s)
@@ -291,18 +293,18 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
       const RnConv& c1 = pl.convs[ci++];
       const RnConv& c2 = pl.convs[ci++];
       const RnConv& c3 = pl.convs[ci++];
-      DIC_TRY(conv_bn(X, c1.d, layers[c1.layer], A, ws.partial, ws.bn, ws.red, train_bn, st));
+      DIC_TRY(conv_bn(X, c1.d, layers[c1.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
       DIC_TRY(bn_apply(A, nullptr, A, c1.d.M(), c1.d.CO, ws.bn, 1, st));
-      DIC_TRY(conv_bn(A, c2.d, layers[c2.layer], Bf, ws.partial, ws.bn, ws.red, train_bn, st));
+      DIC_TRY(conv_bn(A, c2.d, layers[c2.layer], Bf, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
       DIC_TRY(bn_apply(Bf, nullptr, Bf, c2.d.M(), c2.d.CO, ws.bn, 1, st));
       const float* identity = X;
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
-        DIC_TRY(conv_bn(X, ds.d, layers[ds.layer], Cf, ws.partial, ws.bn, ws.red, train_bn, st));
+        DIC_TRY(conv_bn(X, ds.d, layers[ds.layer], Cf, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
         DIC_TRY(bn_apply(Cf, nullptr, Cf, ds.d.M(), ds.d.CO, ws.bn, 0, st));
         identity = Cf;
       }
-      DIC_TRY(conv_bn(Bf, c3.d, layers[c3.layer], A, ws.partial, ws.bn, ws.red, train_bn, st));
+      DIC_TRY(conv_bn(Bf, c3.d, layers[c3.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
       DIC_TRY(bn_apply(A, identity, Bf, c3.d.M(), c3.d.CO, ws.bn, 1, st));      // out = relu(bn3 + identity)
       std::swap(X, Bf);
     }

@@ -58,12 +58,17 @@ struct GemmParams {
   int splitk;           // >1: raw partials go to ws[z][M][N]; splitk_reduce applies the epilogue
   int ktiles_per_split;
   float* ws;
+  // remainder ('tail') tiles: blocks >= tail_first_block each compute 1/tail_split of the K range of one of
+  // the last tiles and leave raw partials in tail_ws; tail_fixup_kernel finishes those tiles (gemm.hip)
+  int tail_first_block, tail_first_tile, tail_split;
+  float* tail_ws;
   int ablate;           // debug/benchmark only: 1 no global traffic in the loop, 2 also no LDS reads, 3 LDS stores but no global loads
   int raw_partials;     // split-K: leave the [splitk][M][N] partial slabs in ws, skip the reduce launch
 };
 
 // host side (gemm.hip)
 size_t gemm_splitk_ws_bytes(int M, int N, int splitk);
+constexpr size_t kGemmTailWsBytes = (size_t)256 * 64 * 64 * sizeof(float);   // tail_ws capacity needed by gemm_launch
 int gemm_pick_tile(int M, int N);               // 128 or 64
 int gemm_launch(GemmParams p, hipStream_t st, int force_tile = 0);
 GemmOperand op_rowk(const float* p, long long ld);

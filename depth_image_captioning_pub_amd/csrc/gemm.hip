@@ -290,31 +290,39 @@ template <int KIND, int BR>
 struct DmaLoader {
   static constexpr int NI = BR / 32;          // wave-instructions per wave and K tile
   const float* p;
-  int K;
-  ConvGeom g;
-  const float* rowptr[NI];
+  int K, C, KW, W;
+  long long lane_off[NI];                     // loop-invariant part of the source offset (floats)
+  unsigned tapmask[NI];                       // IM2COL: bit (kh*KW+kw) set <=> that tap is inside the image
   bool valid[NI];
-  int ih0[NI], iw0[NI];
-  int chunk[NI];                              // pre-swizzled source chunk of this lane
+  int kchunk[NI];                             // ROWK: pre-swizzled chunk * 4 (for the K-tail test)
 
+  // All per-lane address arithmetic happens here, once per output tile; per K tile only a wave-uniform
+  // offset is added (the im2col tap moves every C/32 tiles).
   __device__ __forceinline__ void init(const GemmOperand& op, int r0, int R, int K_) {
-    p = op.p; K = K_; g = op.g;
+    p = op.p; K = K_; C = op.g.C; KW = op.g.KW; W = op.g.W;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int row = (n * 4 + w) * 8 + (lane >> 3);
       const int gr = r0 + row;
       valid[n] = gr < R;
-      chunk[n] = (lane & 7) ^ ((row >> 1) & 7);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      kchunk[n] = chunk * 4;
+      tapmask[n] = 0u;
       if constexpr (KIND == OPK_ROWK) {
-        rowptr[n] = p + (long long)gr * op.ld;
+        lane_off[n] = (long long)gr * op.ld + chunk * 4;
       } else {
+        const ConvGeom& g = op.g;
         const int ohw = g.OH * g.OW;
         const int img = gr / ohw, rem = gr - img * ohw;
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        ih0[n] = oh * g.stride - g.pad;
-        iw0[n] = ow * g.stride - g.pad;
-        rowptr[n] = p + (long long)img * g.H * g.W * g.C;
+        const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+        lane_off[n] = ((long long)img * g.H + ih0) * g.W * g.C + (long long)iw0 * g.C + chunk * 4;
+        unsigned m = 0u;
+        for (int kh = 0; kh < g.KH; ++kh)
+          for (int kw = 0; kw < g.KW; ++kw)
+            if ((unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W) m |= 1u << (kh * g.KW + kw);
+        tapmask[n] = valid[n] ? m : 0u;
       }
     }
   }
@@ -322,24 +330,20 @@ struct DmaLoader {
   // issue the DMA of K tile k0 into `img` (this operand's [BR][32] image of one stage)
   __device__ __forceinline__ void issue(int k0, float* img) const {
     const int w = threadIdx.x >> 6;
-    int kh = 0, kw = 0, c0 = 0;
+    int tap = 0;
+    long long uni = k0;
     if constexpr (KIND == OPK_IM2COL) {
-      const int kpos = k0 / g.C;
-      c0 = k0 - kpos * g.C;
-      kh = kpos / g.KW;
-      kw = kpos - kh * g.KW;
+      tap = k0 / C;
+      const int c0 = k0 - tap * C;
+      const int kh = tap / KW, kw = tap - kh * KW;
+      uni = ((long long)kh * W + kw) * C + c0;
     }
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
-      const float* src = g_zero_line;
-      if constexpr (KIND == OPK_ROWK) {
-        const int k = k0 + chunk[n] * 4;
-        if (valid[n] && k < K) src = rowptr[n] + k;
-      } else {
-        const int ih = ih0[n] + kh, iw = iw0[n] + kw;
-        if (valid[n] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-          src = rowptr[n] + ((long long)ih * g.W + iw) * g.C + c0 + chunk[n] * 4;
-      }
+      bool ok;
+      if constexpr (KIND == OPK_ROWK) ok = valid[n] && (k0 + kchunk[n] < K);
+      else ok = (tapmask[n] >> tap) & 1u;
+      const float* src = ok ? p + lane_off[n] + uni : g_zero_line;
       float* dst = img + ((n * 4 + w) * 8) * BK;            // wave-uniform 1-KiB block
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -347,17 +351,34 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int AK>
+template <int BM, int BN, int AK, int NSTAGE>
 __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int STAGE = (BM + BN) * BK;                        // floats per pipeline stage
-  __shared__ __align__(1024) float smem[2 * STAGE];
+  constexpr int NDMA = BM / 32 + BN / 32;                      // LDS-DMA instructions per wave and K tile
+  __shared__ __align__(1024) float smem[NSTAGE * STAGE];       // ONE LDS object (guide: a second one de-pipelines)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int tiles = p.mtiles * p.ntiles;
-  const int z = lb / tiles, t = lb - z * tiles;
+  const int nk = (p.K + BK - 1) / BK;
+  int z, t, kt0, kt1, tail_slot = -1;
+  if ((int)blockIdx.x < p.tail_first_block) {
+    const int lb = xcd_remap(blockIdx.x, p.tail_first_block);
+    z = lb / tiles;
+    t = lb - z * tiles;
+    kt0 = z * p.ktiles_per_split;
+    kt1 = min(nk, kt0 + p.ktiles_per_split);
+  } else {   // remainder tile, one K slice of it (spreads the last partial round over all CUs)
+    const int q = (int)blockIdx.x - p.tail_first_block;
+    const int piece = q % p.tail_split;
+    t = p.tail_first_tile + q / p.tail_split;
+    z = 0;
+    const int per = (nk + p.tail_split - 1) / p.tail_split;
+    kt0 = piece * per;
+    kt1 = min(nk, kt0 + per);
+    tail_slot = q;
+  }
   const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
 
   DmaLoader<AK, BM> la;
@@ -365,10 +386,7 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
   la.init(p.A, tm * BM, p.M, p.K);
   lbld.init(p.B, tn * BN, p.N, p.K);
 
-  const int nk = (p.K + BK - 1) / BK;
-  const int kt0 = z * p.ktiles_per_split;
-  const int kt1 = min(nk, kt0 + p.ktiles_per_split);
-  const int nkt = kt1 - kt0;
+  const int nkt = max(kt1 - kt0, 0);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -378,11 +396,13 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nkt > 0) {
-    la.issue(kt0 * BK, smem);
-    lbld.issue(kt0 * BK, smem + BM * BK);
-  }
-  __syncthreads();          // (vmcnt(0) + barrier: hipcc drains the LDS-DMA before the barrier)
+  // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nkt) {
+      la.issue((kt0 + s0) * BK, smem + s0 * STAGE);
+      lbld.issue((kt0 + s0) * BK, smem + s0 * STAGE + BM * BK);
+    }
 
   // fragment addressing: row = wave offset + 32*t + (lane&31); swizzle key (row>>1)&7 depends on the lane only
   const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 1) & 7;
@@ -392,12 +412,65 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
   const int aoff = (wm * WM + i31) * BK, boff = BM * BK + (wn * WN + i31) * BK;
 
   for (int it = 0; it < nkt; ++it) {
-    const float* st = smem + (it & 1) * STAGE;
-    if (it + 1 < nkt) {
-      float* nx = smem + ((it + 1) & 1) * STAGE;
-      la.issue((kt0 + it + 1) * BK, nx);
-      lbld.issue((kt0 + it + 1) * BK, nx + BM * BK);
+    // RAW: this wave's DMA of tile `it` has landed once at most the younger tiles' instructions are outstanding
+    // (vmcnt counts in issue order); the barrier then covers the other waves' pieces.  WAR: the stage refilled
+    // below was last read in iteration it-1, which every wave has left when it passes this barrier.
+    if (NSTAGE == 2 || it + NSTAGE - 2 >= nkt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
+    constexpr bool kAsmPath = (TM == 1 && TN == 1);
+    const bool more = it + NSTAGE - 1 < nkt;
+    float* nx = smem + ((it + NSTAGE - 1) % NSTAGE) * STAGE;
+    if (!kAsmPath && more) {
+      la.issue((kt0 + it + NSTAGE - 1) * BK, nx);
+      lbld.issue((kt0 + it + NSTAGE - 1) * BK, nx + BM * BK);
+    }
+    if constexpr (kAsmPath) {
+      // Fragment reads in inline asm: hipcc would otherwise drain the DMA ring (vmcnt(0)) before every ds_read
+      // that follows an LDS-DMA issue, because it cannot prove the two do not alias.  The asm reads are not
+      // tracked by the compiler, so lgkmcnt is counted here: issue order a0,b0,a1,b1,a2,b2,a3,b3; lgkmcnt(4)
+      // retires the first four, the second statement (tied to the remaining registers) retires the rest.
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem +
+                             (unsigned)((it % NSTAGE) * STAGE) * 4u;
+      const unsigned aa = sbase + (unsigned)aoff * 4u, bb = sbase + (unsigned)boff * 4u;
+      v4f a0, a1, a2, a3, b0, b1, b2, b3;
+      asm volatile(
+          "ds_read_b128 %0, %8\n\t"
+          "ds_read_b128 %4, %12\n\t"
+          "ds_read_b128 %1, %9\n\t"
+          "ds_read_b128 %5, %13\n\t"
+          "ds_read_b128 %2, %10\n\t"
+          "ds_read_b128 %6, %14\n\t"
+          "ds_read_b128 %3, %11\n\t"
+          "ds_read_b128 %7, %15\n\t"
+          "s_waitcnt lgkmcnt(4)"
+          : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+          : "v"(aa + pos[0] * 4u), "v"(aa + pos[1] * 4u), "v"(aa + pos[2] * 4u), "v"(aa + pos[3] * 4u),
+            "v"(bb + pos[0] * 4u), "v"(bb + pos[1] * 4u), "v"(bb + pos[2] * 4u), "v"(bb + pos[3] * 4u)
+          : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#define DIC_MFMA4(A_, B_)                                                                     \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, acc[0][0], 0, 0, 0);           \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, acc[0][0], 0, 0, 0);           \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, acc[0][0], 0, 0, 0);           \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, acc[0][0], 0, 0, 0);
+      DIC_MFMA4(a0, b0)
+      if (more) la.issue((kt0 + it + NSTAGE - 1) * BK, nx);          // address math + DMA in the MFMA shadow
+      DIC_MFMA4(a1, b1)
+      if (more) lbld.issue((kt0 + it + NSTAGE - 1) * BK, nx + BM * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a2), "+v"(a3), "+v"(b2), "+v"(b3)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_MFMA4(a2, b2)
+      DIC_MFMA4(a3, b3)
+#undef DIC_MFMA4
+    } else {
+    const float* st = smem + (it % NSTAGE) * STAGE;
     float4 af[TM][4], bf[TN][4];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -417,9 +490,73 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][gq].z, bf[j][gq].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][gq].w, bf[j][gq].w, acc[i][j], 0, 0, 0);
         }
-    __syncthreads();
+    }
+  }
+  __syncthreads();      // all fragment reads done before the epilogue reuses LDS as scratch
+  if (tail_slot >= 0) {   // raw partial of this K slice, tile-local [BM][BN] layout
+    float* dst = p.tail_ws + (long long)tail_slot * BM * BN;
+    const int nl = wn * WN + (lane & 31), ml = wm * WM + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dst[(ml + i * 32 + (r & 3) + 8 * (r >> 2)) * BN + nl + j * 32] = acc[i][j][r];
+    return;
   }
   gemm_epilogue<BM, BN>(p, acc, tm, tn, z, smem);
+}
+
+// Finishes the remainder tiles of a tail-split launch: sums the K-slice partials, applies the epilogue and writes
+// the BatchNorm column partials of that tile.  grid = remainder tiles; 256 threads = 16 column quads x 16 row
+// groups of 4 rows; every thread first gathers all its slice values with independent 16-B loads.
+__global__ void __launch_bounds__(256) tail_fixup_kernel(const GemmParams p) {
+  constexpr int BM = 64, BN = 64;
+  __shared__ float4 sred[2][16][16];
+  const int t = p.tail_first_tile + blockIdx.x;
+  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const float* base = p.tail_ws + (long long)blockIdx.x * p.tail_split * BM * BN + (rg * 4) * BN + c4 * 4;
+  float4 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < p.tail_split; ++s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 x = *reinterpret_cast<const float4*>(base + (long long)s * BM * BN + r * BN);
+      v[r].x += x.x; v[r].y += x.y; v[r].z += x.z; v[r].w += x.w;
+    }
+  }
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cs2 = cs;
+  const int n = tn * BN + c4 * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = tm * BM + rg * 4 + r;
+    if (m < p.M) {
+      float e[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < p.N) o[j] = finalize_store(p.ep, m, n + j, e[j]);
+      cs.x += o[0]; cs.y += o[1]; cs.z += o[2]; cs.w += o[3];
+      cs2.x += o[0] * o[0]; cs2.y += o[1] * o[1]; cs2.z += o[2] * o[2]; cs2.w += o[3] * o[3];
+    }
+  }
+  if (p.ep.stats) {
+    sred[0][rg][c4] = cs;
+    sred[1][rg][c4] = cs2;
+    __syncthreads();
+    if (rg < 2) {     // rg 0: sums, rg 1: sums of squares; fixed order over the 16 row groups
+      float4 a = sred[rg][0][c4];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) { const float4 b = sred[rg][i][c4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      float o[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < p.N) p.ep.stats[((long long)tm * 2 + rg) * p.N + n + j] = o[j];
+    }
+  }
 }
 
 template <int BM, int BN, int AK, int BKIND, int ABL = 0>
@@ -531,7 +668,17 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
 struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
 static bool g_prof_on = false;
 static bool g_force_v1 = false;   // benchmarking switch: register-staged kernel for every shape
-void gemm_force_v1(int on) { g_force_v1 = on != 0; }
+static int g_dma_stages = 2;
+static bool g_tail_split_on = true;
+static bool g_tail_skip_fix = false;   // timing experiment only
+void gemm_force_v1(int on) {
+  g_force_v1 = (on == 1);
+  if (on == 2 || on == 3) g_dma_stages = on;
+  if (on == 10) g_tail_split_on = false;
+  if (on == 11) g_tail_split_on = true;
+  if (on == 12) g_tail_skip_fix = true;
+  if (on == 13) g_tail_skip_fix = false;
+}
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 
@@ -653,6 +800,7 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   DIC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: bad shape %d %d %d", p.M, p.N, p.K);
   DIC_REQUIRE(p.A.p && p.B.p && p.ep.C, "gemm: null pointer");
   if (p.A.kind == OPK_IM2COL) DIC_REQUIRE(p.A.g.C % 32 == 0, "im2col loader needs C %% 32 == 0 (C=%d)", p.A.g.C);
+  const bool taps_ok = p.A.kind != OPK_IM2COL || p.A.g.KH * p.A.g.KW <= 32;      // v2 keeps a per-tap bitmask
   if (p.B.kind == OPK_IM2COL_COLK) DIC_REQUIRE(p.B.g.C % 4 == 0, "im2col_colk loader needs C %% 4 == 0");
   const int tile = force_tile ? force_tile : gemm_pick_tile(p.M, p.N);
   p.mtiles = ceil_div(p.M, tile);
@@ -667,8 +815,28 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     DIC_REQUIRE(p.ep.stats == nullptr, "gemm: BN statistics epilogue cannot be combined with split-K");
   }
   if (p.ep.alpha == 0.0f) p.ep.alpha = 1.0f;
-  const bool dma_ok = (p.B.kind == OPK_ROWK && p.B.vec && (p.K % 4 == 0) && p.ablate == 0 && !g_force_v1 &&
+  const bool dma_ok = (p.B.kind == OPK_ROWK && p.B.vec && (p.K % 4 == 0) && p.ablate == 0 && !g_force_v1 && taps_ok &&
                        (p.A.kind == OPK_IM2COL || (p.A.kind == OPK_ROWK && p.A.vec)));
+  // Tail plan (v2, 64-tile, no split-K): T tiles on 256 CUs leave r = T mod 256 tiles for a last partial round;
+  // when r is small those tiles are cut into s = floor(256/r) K slices (<= 256 extra workgroups of 1/s tile each)
+  // so the remainder spreads over the whole chip instead of costing a full round (measured: 784 tiles cost as much
+  // as 1024 without this).
+  int total_blocks = p.mtiles * p.ntiles * p.splitk;
+  p.tail_first_block = total_blocks; p.tail_first_tile = 0; p.tail_split = 1;
+  int tail_tiles = 0;
+  if (dma_ok && tile == 64 && p.splitk == 1 && p.tail_ws != nullptr && g_tail_split_on) {
+    const int T = p.mtiles * p.ntiles, r = T % 256;
+    int s = r > 0 ? 256 / r : 0;
+    s = std::min(s, std::min(nk / 2, 16));
+    if (r > 0 && r <= 128 && s >= 2) {
+      tail_tiles = r;
+      p.tail_first_tile = T - r;
+      p.tail_first_block = T - r;
+      p.tail_split = s;
+      total_blocks = (T - r) + r * s;
+    }
+  }
+  if (tail_tiles == 0) p.tail_ws = nullptr;
   ProfRec rec{};
   if (g_prof_on) {
     rec.e0 = prof_event(); rec.e1 = prof_event();
@@ -678,19 +846,26 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   }
   int rc = DIC_OK;
   if (dma_ok) {
-    const dim3 grid(p.mtiles * p.ntiles * p.splitk), block(256);
+    const dim3 grid(total_blocks), block(256);
     if (tile == 128) {
-      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_IM2COL>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_ROWK>), grid, block, 0, st, p);
+      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_IM2COL, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_ROWK, 2>), grid, block, 0, st, p);
+    } else if (g_dma_stages == 2) {
+      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_IM2COL, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_ROWK, 2>), grid, block, 0, st, p);
     } else {
-      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_IM2COL>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_ROWK>), grid, block, 0, st, p);
+      if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_IM2COL, 3>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_ROWK, 3>), grid, block, 0, st, p);
     }
   } else {
     rc = (tile == 128) ? launch_tile<128, 128>(p, st) : launch_tile<64, 64>(p, st);
   }
   if (rc != 0) return rc;
   DIC_LAUNCH_CHECK();
+  if (tail_tiles > 0 && !g_tail_skip_fix) {
+    hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(256), 0, st, p);
+    DIC_LAUNCH_CHECK();
+  }
   if (g_prof_on) {
     (void)hipEventRecord(rec.e1, st);
     g_prof_recs.push_back(rec);

@@ -131,6 +131,12 @@ class CaptionTrainer:
         self.dec_ws: Optional[torch.Tensor] = None
         self.enc_ws: Optional[torch.Tensor] = None
         self.last = {}
+        # software pipelining of the frozen RGB encoder: features of the NEXT batch are computed on a side
+        # stream while the rest of the current step runs (see prefetch_features)
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.feat_bufs = [None, None]
+        self.feat_flip = 0
+        self.prefetched = None         # (imgs tensor, features, done-event)
         self.keep_outputs = False      # True: keep logits intact (loss gradient not written in place)
         self.timing = False            # True: record stage-boundary events on the current stream
         self.marks = []
@@ -148,6 +154,25 @@ class CaptionTrainer:
             out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
         return out
 
+    def prefetch_features(self, imgs: torch.Tensor) -> None:
+        """Launch the frozen ResNet-152 forward of an upcoming batch on the side stream.  Legal because the RGB
+        encoder takes no gradient and is not touched by the optimiser (depth_train.py:136): its output for batch
+        i+1 does not depend on the update of step i; its BatchNorm running statistics are still updated once per
+        batch, in batch order (all ResNet work is serialised on the one side stream)."""
+        B = imgs.shape[0]
+        i = self.feat_flip
+        self.feat_flip ^= 1
+        if self.feat_bufs[i] is None or self.feat_bufs[i].shape[0] != B:
+            self.feat_bufs[i] = torch.empty((B, native.L_CELLS, native.D_ENC), dtype=torch.float32, device=self.device)
+        ready = torch.cuda.Event()
+        ready.record()                                   # inputs + previous readers of this buffer are done
+        with torch.cuda.stream(self.side_stream):
+            self.side_stream.wait_event(ready)
+            feats = self.resnet.forward(imgs, train_bn=True, out=self.feat_bufs[i])
+            done = torch.cuda.Event()
+            done.record(self.side_stream)
+        self.prefetched = (imgs, feats, done)
+
     # ---- pieces -----------------------------------------------------------------------------
     def encode(self, imgs: torch.Tensor, depth_map: torch.Tensor, train: bool):
         feats = self.resnet.forward(imgs, train_bn=train)                                   # depth_train.py:179
@@ -158,14 +183,23 @@ class CaptionTrainer:
 
     def train_step(self, imgs: torch.Tensor, depth_map: torch.Tensor, captions: torch.Tensor, lengths: Sequence[int],
                    drop_mult: Optional[torch.Tensor] = None, gumbel_u: Optional[torch.Tensor] = None,
-                   temp: float = 1.0, precomputed_features: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync)."""
+                   temp: float = 1.0, precomputed_features: Optional[torch.Tensor] = None,
+                   next_imgs: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync).
+        next_imgs: images of the following batch; their (frozen) ResNet forward is overlapped with this step."""
         B = imgs.shape[0] if imgs is not None else precomputed_features.shape[0]
         tmax = max(lengths) - 1
         self.marks = []
         self._mark("start")
         if precomputed_features is None:
-            feats = self.resnet.forward(imgs, train_bn=True)                                # depth_train.py:179
+            if self.prefetched is not None and self.prefetched[0] is imgs:
+                _, feats, done = self.prefetched
+                torch.cuda.current_stream().wait_event(done)
+                self.prefetched = None
+            else:
+                feats = self.resnet.forward(imgs, train_bn=True)                            # depth_train.py:179
+            if next_imgs is not None:
+                self.prefetch_features(next_imgs)
             self._mark("resnet152_fwd")
             fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
                                                        workspace=self.enc_ws)               # :204-206

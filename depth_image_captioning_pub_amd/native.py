@@ -303,7 +303,7 @@ class ResNetRunner:
             self.keep.append(tens)
         self.workspace: Optional[torch.Tensor] = None
 
-    def forward(self, imgs: torch.Tensor, train_bn: bool) -> torch.Tensor:
+    def forward(self, imgs: torch.Tensor, train_bn: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         lib = _lib.load()
         x = _dev_f32(imgs, "imgs")
         B, c, H, W = x.shape
@@ -313,7 +313,8 @@ class ResNetRunner:
         need = lib.dic_resnet_workspace_bytes(B, H, W, self.blocks)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
-        out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=x.device)
         rc = lib.dic_resnet_fwd(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, ptr(out),
                                 ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
         check(rc, "dic_resnet_fwd")

@@ -43,10 +43,11 @@ int dic_gemm_f32(int M, int N, int K, const float* A, long long lda, int a_colk,
  *      Depth_CNN_endoder.features, depth_models.py:19-23,36-47, and torchvision ResNet-152 under
  *      CNNEncoder_Atten.backbone, base_caption_models.py:23-30).  x may be NCHW when in_nchw=1
  *      (first layer: the reference feeds NCHW images).  bn_partial (nullable) receives per-M-tile
- *      column sums / sums of squares [mtiles][2][CO] for train-mode BatchNorm statistics. */
+ *      column sums / sums of squares [mtiles][2][CO] for train-mode BatchNorm statistics.  tail_ws (nullable):
+ *      4 MiB of scratch that lets the launcher K-split the remainder tiles of the last partial round. */
 int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, const float* w_ohwi, const float* bias,
                    int CO, int KH, int KW, int stride, int pad, float* y_nhwc, float* bn_partial, int* mtiles_out,
-                   int force_tile, void* stream);
+                   int force_tile, float* tail_ws, void* stream);
 
 
 /* ---- decoder: CD_RNNDecoderWith{Soft,Hard}Attention (Depth_caption_model/depth_models.py:96-305,

@@ -6,6 +6,7 @@ from depth_image_captioning_pub_amd import _lib
 from depth_image_captioning_pub_amd._lib import ptr, stream_ptr, check
 lib = _lib.load()
 DEV = "cuda:0"
+TAIL = torch.empty(256*64*64, device="cuda:0") if "--tail" in __import__("sys").argv else None
 def timeit(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -26,10 +27,12 @@ def conv(Bn, H, Cc, CO, k, s, p, tile, stats=True):
     M = Bn*OH*OH
     part = torch.empty((M//64+2)*2*CO, device=DEV)
     mt = C.c_int(0)
-    def f(): check(lib.dic_conv2d_fwd(ptr(x), Bn, H, H, Cc, 0, ptr(w), None, CO, k, k, s, p, ptr(y), ptr(part) if stats else None, C.byref(mt), tile, stream_ptr()))
+    def f(): check(lib.dic_conv2d_fwd(ptr(x), Bn, H, H, Cc, 0, ptr(w), None, CO, k, k, s, p, ptr(y), ptr(part) if stats else None, C.byref(mt), tile, ptr(TAIL), stream_ptr()))
     us = timeit(f)
     fl = 2*M*CO*k*k*Cc
     print(f"conv  M={M:7d} N={CO:5d} K={k*k*Cc:5d} tile {tile:3d} stats={int(stats)}: {us:8.1f} us  {fl/us/1e6:6.1f} TF  tiles={(-(-M//tile))*(-(-CO//tile))}", flush=True)
+import sys as _s
+if len(_s.argv) > 1 and _s.argv[1].isdigit(): lib.dic_debug_force_staged_gemm(int(_s.argv[1])); print("force =", _s.argv[1])
 gemm(4096, 4096, 4096, 128); gemm(4096, 4096, 4096, 64)
 gemm(8192, 8192, 1024, 128)
 for tile in (64, 128):
