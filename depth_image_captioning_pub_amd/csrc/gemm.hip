@@ -828,7 +828,8 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     const int T = p.mtiles * p.ntiles, r = T % 256;
     int s = r > 0 ? 256 / r : 0;
     s = std::min(s, std::min(nk / 2, 16));
-    if (r > 0 && r <= 128 && s >= 2) {
+    // worth a fix-up launch (~8 us) only on shallow grids, where one partial round is a big share of the time
+    if (r > 0 && r <= 128 && s >= 2 && T < 7 * 256) {
       tail_tiles = r;
       p.tail_first_tile = T - r;
       p.tail_first_block = T - r;

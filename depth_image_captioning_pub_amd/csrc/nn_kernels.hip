@@ -10,19 +10,20 @@ static inline int ew_blocks(long long n_items) { return (int)std::min<long long>
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics -> scale/shift
 // ------------------------------------------------------------------------------------------
-// Stage 1: grid (C/32, S): 256 threads = 32 channels x 8 tile-lanes reduce one slice of the conv epilogue's
-// per-M-tile partials in fp64 -> red[S][2][C].  Stage 2: one thread per channel sums the S slices and produces
-// scale/shift (+ saved mean/invstd, running-stat update).  Two short launches instead of one long serial loop.
-constexpr int kBnSliceTiles = 64;     // M tiles per stage-1 workgroup
-__global__ void __launch_bounds__(256) bn_stats_slice_kernel(const float* __restrict__ partial, int mtiles, int C,
-                                                              double* __restrict__ red) {
-  __shared__ double s1[8][32], s2[8][32];
+// One launch: workgroup = 32 channels x 32 tile-lanes (1024 threads) reduces the conv epilogue's per-M-tile
+// partials [mtiles][2][C] in fp64 (fixed order: lane-strided partial sums, then a fixed LDS tree) and produces
+// scale/shift (+ saved mean/invstd, running-stat update).  Deep layers have <= 200 M tiles -> <= 7 iterations.
+__global__ void __launch_bounds__(1024) bn_finalize_train_kernel(const float* __restrict__ partial, int mtiles,
+                                                                  double count, int C, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                  BnBuf out) {
+  __shared__ double s1[32][33], s2[32][33];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  const int t0 = blockIdx.y * kBnSliceTiles, t1 = min(mtiles, t0 + kBnSliceTiles);
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int t = t0 + g; t < t1; t += 8) {
+    for (int t = g; t < mtiles; t += 32) {
       a += (double)partial[((long long)t * 2 + 0) * C + c];
       b += (double)partial[((long long)t * 2 + 1) * C + c];
     }
@@ -30,37 +31,21 @@ __global__ void __launch_bounds__(256) bn_stats_slice_kernel(const float* __rest
   __syncthreads();
   if (g == 0 && c < C) {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { a += s1[i][cl]; b += s2[i][cl]; }
-    red[((long long)blockIdx.y * 2 + 0) * C + c] = a;
-    red[((long long)blockIdx.y * 2 + 1) * C + c] = b;
-  }
-}
-
-__global__ void __launch_bounds__(256) bn_finalize_train_kernel(const double* __restrict__ red, int slices, double count,
-                                                                 int C, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta,
-                                                                 float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                 BnBuf out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int s = 0; s < slices; ++s) {
-    a += red[((long long)s * 2 + 0) * C + c];
-    b += red[((long long)s * 2 + 1) * C + c];
-  }
-  const double mean = a / count;
-  double var = b / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = 1.0f / sqrtf((float)var + kBnEps);
-  const float sc = gamma[c] * invstd;
-  out.scale[c] = sc;
-  out.shift[c] = beta[c] - (float)mean * sc;
-  out.mean[c] = (float)mean;
-  out.invstd[c] = invstd;
-  if (rmean) {
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
-    rvar[c] = (1.f - kBnMomentum) * rvar[c] + kBnMomentum * (float)unb;
+    for (int i = 1; i < 32; ++i) { a += s1[i][cl]; b += s2[i][cl]; }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = 1.0f / sqrtf((float)var + kBnEps);
+    const float sc = gamma[c] * invstd;
+    out.scale[c] = sc;
+    out.shift[c] = beta[c] - (float)mean * sc;
+    out.mean[c] = (float)mean;
+    out.invstd[c] = invstd;
+    if (rmean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
+      rvar[c] = (1.f - kBnMomentum) * rvar[c] + kBnMomentum * (float)unb;
+    }
   }
 }
 
@@ -78,16 +63,13 @@ __global__ void __launch_bounds__(256) bn_finalize_eval_kernel(int C, const floa
   out.invstd[c] = invstd;
 }
 
-size_t bn_finalize_ws_doubles(long long max_mtiles, int C) {
-  return (size_t)ceil_div(max_mtiles, kBnSliceTiles) * 2 * (size_t)C;
-}
+size_t bn_finalize_ws_doubles(long long max_mtiles, int C) { return 16; }   // (kept for ABI stability; unused)
 
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, BnBuf out, double* red, hipStream_t st) {
-  const int slices = ceil_div(mtiles, kBnSliceTiles);
-  hipLaunchKernelGGL(bn_stats_slice_kernel, dim3(ceil_div(C, 32), slices), dim3(256), 0, st, partial, mtiles, C, red);
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)red, slices,
-                     (double)count, C, gamma, beta, running_mean, running_var, out);
+  (void)red;
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partial, mtiles, (double)count,
+                     C, gamma, beta, running_mean, running_var, out);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -424,7 +406,30 @@ int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float
   return DIC_OK;
 }
 
-// column sums with a fixed two-stage tree (deterministic)
+// column sums with a fixed two-stage tree (deterministic).  Stage 1: block = 64 channels (16 float4 lanes) x 16 row
+// lanes over one of 64 row chunks -> ws[chunk][C]; stage 2 sums the 64 chunk rows.  (C % 4 == 0; else scalar path)
+__global__ void __launch_bounds__(256) colsum_rows_v4_kernel(const float* __restrict__ X, long long ld, long long rows,
+                                                              int C, float* __restrict__ out) {
+  __shared__ float4 sa[16][16];
+  const int c4l = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4l * 4;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C)
+    for (long long r = r0 + rl; r < r1; r += 16) {
+      const float4 g = *reinterpret_cast<const float4*>(X + r * ld + c);
+      a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+    }
+  sa[rl][c4l] = a;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { a.x += sa[i][c4l].x; a.y += sa[i][c4l].y; a.z += sa[i][c4l].z; a.w += sa[i][c4l].w; }
+    *reinterpret_cast<float4*>(out + (long long)blockIdx.y * C + c) = a;
+  }
+}
+
 __global__ void __launch_bounds__(256) colsum_rows_kernel(const float* __restrict__ X, long long ld, long long rows,
                                                            int C, float* __restrict__ out, int chunks) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -437,6 +442,15 @@ __global__ void __launch_bounds__(256) colsum_rows_kernel(const float* __restric
 }
 
 int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st) {
+  const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && rows >= 256;
+  if (v4) {
+    const int chunks = 64;
+    hipLaunchKernelGGL(colsum_rows_v4_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, X, ld, rows, C, ws);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, ws, (long long)C,
+                       (long long)chunks, C, out, 1);
+    DIC_LAUNCH_CHECK();
+    return DIC_OK;
+  }
   const int chunks = (int)std::min<long long>(256, std::max<long long>(1, rows / 16));
   if (chunks > 1) {
     hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), chunks), dim3(256), 0, st, X, ld, rows, C, ws, chunks);
