@@ -60,12 +60,29 @@ def profile_step(trainer, args_step):
     rows = []
     for i in range(nout.value):
         k = keys[i]
+        dma = k >= 1000
+        k %= 1000
         tile = 128 if k >= 100 else 64
         a, b = (k % 100) // 10, k % 10
-        rows.append({"kernel": f"gemm_kernel<{tile},{tile},{KIND_NAMES[a]},{KIND_NAMES[b]}>", "launches": int(cnt[i]),
-                     "total_ms": ms[i], "flops": fl[i]})
+        name = (f"gemm_dma_kernel<{tile},{tile},{KIND_NAMES[a]}>" if dma
+                else f"gemm_kernel<{tile},{tile},{KIND_NAMES[a]},{KIND_NAMES[b]}>")
+        rows.append({"kernel": name, "rocprof_name": (f"gemm_dma_kernel<{tile}, {tile}, {a}, 2>" if dma else
+                                                       f"gemm_kernel<{tile}, {tile}, {a}, {b}, 0>"),
+                     "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i]})
     rows.sort(key=lambda r: -r["total_ms"])
     return rows
+
+
+def pmc_for(rocprof_name: str):
+    """(HBM bytes per launch, MFMA utilisation) of a kernel from the committed PMC summary, or (None, None)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")
+    try:
+        for rec in json.load(open(path)):
+            if rocprof_name in rec["kernel"]:
+                return round(rec["hbm_bytes_per_launch_corrected"]), round(rec.get("mfma_util", 0.0), 4) or None
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline(sample_b: int, iters: int):
@@ -183,8 +200,12 @@ def main():
     if rank == 0:
         top = prof[0]
         ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
+        traffic, mfma_util = pmc_for(top["rocprof_name"])
         roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE x2 gfx950 "
+                                    "wide-read correction + WRITE_SIZE, KB->bytes), profiles/r01_pmc_per_kernel.json",
+                    "mfma_util_pmc": mfma_util,
                     "launches_per_step": top["launches"],
                     "avg_launch_us": round(top["total_ms"] * 1e3 / top["launches"], 2),
                     "all_contraction_kernels": [

@@ -842,7 +842,7 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   if (g_prof_on) {
     rec.e0 = prof_event(); rec.e1 = prof_event();
     rec.flops = 2.0 * p.M * p.N * (double)p.K;
-    rec.key = (tile == 128 ? 100 : 0) + p.A.kind * 10 + p.B.kind;
+    rec.key = (dma_ok ? 1000 : 0) + (tile == 128 ? 100 : 0) + p.A.kind * 10 + p.B.kind;
     (void)hipEventRecord(rec.e0, st);
   }
   int rc = DIC_OK;

@@ -183,7 +183,7 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
 
 /* ---- measurement aid (bench.py roofline): per-launch HIP events around every MFMA contraction launch,
  *      recorded on the launch stream; dic_profile_end synchronises and returns, per kernel instantiation
- *      (key = 100*(tile==128) + 10*A_kind + B_kind), total milliseconds, algorithmic FLOPs and launches. */
+ *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind), total milliseconds, algorithmic FLOPs and launches. */
 /* benchmarking aid: 1 = run every contraction on the register-staged kernel (v1) instead of the LDS-DMA one */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);
