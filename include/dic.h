@@ -181,6 +181,21 @@ size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks);
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
                    int H, int W, int train_bn, float* features, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- host data path on the device: the tensor work of util.collate_func_for_dep
+ *      (Captioning_models/util.py:13-17,100-101), DPT_Depthestimator.standardize_depth_map
+ *      (Depth_caption_model/DPT_model.py:43-61) and the depth cache lookup (depth_train.py:196-202). */
+/* out = (in - mean[c]) / std[c], NCHW, C <= 3; mean3/std3 are HOST arrays (T.Normalize, util.py:13). */
+int dic_normalize_images(const float* in, float* out, int B, int C, int H, int W, const float* mean3, const float* std3,
+                         void* stream);
+/* T.Resize(resize_short, bilinear) + T.CenterCrop(crop) + y*mul+add over `planes` HxW planes (util.py:14-17;
+ * align_corners=False, no antialias = torchvision's result when up-scaling 224 -> 384). out: [planes,crop,crop]. */
+int dic_resize_bilinear(const float* in, int planes, int H, int W, int resize_short, int crop, float mul, float add,
+                        float* out, void* stream);
+/* in place: NaN -> 0.5, then per-image (x-min)/(max-min)   (DPT_model.py:50-59); depth: [B, hw]. */
+int dic_depth_standardize(float* depth, int B, long long hw, void* stream);
+/* out[r,:] = table[idx[r],:] (rows of row_floats floats, % 4 == 0; idx int64 on device): depth cache lookup. */
+int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row_floats, float* out, void* stream);
+
 /* ---- measurement aid (bench.py roofline): per-launch HIP events around every MFMA contraction launch,
  *      recorded on the launch stream; dic_profile_end synchronises and returns, per kernel instantiation
  *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind), total milliseconds, algorithmic FLOPs and launches. */

@@ -1,0 +1,53 @@
+"""GPU: device side of the data path against torch CPU ops (what torchvision's transforms reduce to)."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from depth_image_captioning_pub_amd.Captioning_models import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_normalise_and_resize(lib):
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 3, 224, 224, generator=g)
+    m = torch.tensor(util.IMAGENET_MEAN).view(1, 3, 1, 1)
+    s = torch.tensor(util.IMAGENET_STD).view(1, 3, 1, 1)
+    assert torch.allclose(util.norm_trans(x.to(DEV)).cpu(), (x - m) / s, atol=1e-6)
+    ref = (F.interpolate(x, size=(384, 384), mode="bilinear", align_corners=False) - 0.5) / 0.5
+    assert torch.allclose(util.dep_trans(x.to(DEV)).cpu(), ref, atol=2e-6)
+    xr = torch.rand(2, 3, 100, 150, generator=g)                             # non-square: short edge -> 384, centre crop
+    r = F.interpolate(xr, size=(384, 576), mode="bilinear", align_corners=False)[:, :, :, 96:480]
+    assert torch.allclose(util.dep_trans(xr.to(DEV)).cpu(), (r - 0.5) / 0.5, atol=2e-6)
+
+
+def test_depth_standardise_and_cache(lib):
+    g = torch.Generator().manual_seed(2)
+    d = torch.randn(4, 1, 224, 224, generator=g) * 3 + 1
+    d[1, 0, 5, 7] = float("nan")
+    ref = torch.nan_to_num(d, nan=0.5)
+    mx = ref.flatten(2, 3).max(dim=2).values.view(4, 1, 1, 1)
+    mn = ref.flatten(2, 3).min(dim=2).values.view(4, 1, 1, 1)
+    ref = (ref - mn) / (mx - mn)                                              # DPT_model.py:50-59
+    out = util.standardize_depth_map(d.to(DEV))
+    assert torch.allclose(out.cpu(), ref, atol=1e-6)
+    cache = util.DepthCache(8, device=DEV)
+    keys = [f"caps-{i}" for i in range(4)]
+    cache.put(keys, out)
+    got = cache.get([keys[2], keys[0], keys[2]])
+    assert torch.equal(got.cpu(), out.cpu()[[2, 0, 2]])
+
+
+def test_collate_for_dep_end_to_end(lib):
+    random.seed(3)
+    w2i = {"a": 0, "man": 1, "rides": 2, "<start>": 3, "<end>": 4, "<unk>": 5, "<null>": 6}
+    g = torch.Generator().manual_seed(4)
+    batch = [(torch.rand(3, 224, 224, generator=g), [c] * 5) for c in ("a man", "a man rides a man", "a")]
+    imgs, imgs_dep, targets, lengths, allcaps = util.collate_func_for_dep(batch, w2i, device=DEV)
+    assert lengths == sorted(lengths, reverse=True) == [7, 4, 3]
+    assert imgs.shape == (3, 3, 224, 224) and imgs_dep.shape == (3, 3, 384, 384) and imgs.is_cuda
+    assert targets.shape == (3, 7) and int(targets[2, 3]) == w2i["<null>"]
+    assert allcaps[0].startswith("a man rides")
