@@ -77,6 +77,21 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over each 32-
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// fp32 -> three bf16 planes (hi, mid, lo), round-to-nearest-even at each step; hi+mid+lo == x exactly
+__device__ __forceinline__ unsigned short bf16_rne_bits(float x) {
+  unsigned int u = __float_as_uint(x);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);       // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+__device__ __forceinline__ void split3_bf16(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+  h = bf16_rne_bits(v);
+  const float r1 = v - bf16_bits_to_f32(h);
+  m = bf16_rne_bits(r1);
+  l = bf16_rne_bits(r1 - bf16_bits_to_f32(m));
+}
+
 // Bijective XCD-aware block remap (guide T1): blocks b and b+8 share an XCD (speed only).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;

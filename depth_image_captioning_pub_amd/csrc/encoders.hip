@@ -145,6 +145,7 @@ static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
 
 struct RnWs {
   float* act[4];
+  unsigned short* planes[3][3];     // bf16x3 mode: three rotating activation buffers x (hi, mid, lo)
   float* partial;
   float* tail;
   double* red;
@@ -152,10 +153,13 @@ struct RnWs {
   size_t bytes;
 };
 
-static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, bool* ov) {
+static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov) {
   Carver c(p, bytes);
   RnWs w{};
   for (int i = 0; i < 4; ++i) w.act[i] = c.take<float>(pl.max_act);
+  if (mode == 1)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) w.planes[i][j] = c.take<unsigned short>(pl.max_act);
   w.partial = c.take<float>(pl.max_partial);
   w.red = c.take<double>(pl.max_red);
   w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
@@ -173,6 +177,60 @@ static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L
   if (train_bn)
     return bn_finalize_train(partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, red, st);
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+}
+
+// conv (bf16x3 planes in, raw fp32 out) -> BN scale/shift
+static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, const dic_conv_bn_layer& L, float* y,
+                       const RnWs& ws, int train_bn, hipStream_t st) {
+  int mtiles = 0;
+  const unsigned short* xp[3] = {x_planes[0], x_planes[1], x_planes[2]};
+  const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
+  DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st));
+  if (train_bn)
+    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, ws.bn,
+                             ws.red, st);
+  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, ws.bn, st);
+}
+
+// ResNet forward with the bf16x3 convolution: every activation that feeds a convolution is kept as three bf16 planes
+// (written by the BatchNorm-apply kernels), block outputs additionally in fp32 for the residual connection.
+static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, const float* imgs_nchw, int B, int train_bn,
+                          float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st) {
+  size_t ci = 0;
+  float *X = ws.act[0], *A = ws.act[1], *Bf = ws.act[2], *Cf = ws.act[3];
+  unsigned short* const* Xp = ws.planes[0];
+  unsigned short* const* P1 = ws.planes[1];
+  unsigned short* const* P2 = ws.planes[2];
+  {   // stem (C_in = 3, 1 % of the FLOPs): exact-fp32 gather kernel, then BN + ReLU + maxpool, then split into planes
+    const RnConv& c = pl.convs[ci++];
+    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
+    DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
+    const int ph = (c.d.OH() + 2 - 3) / 2 + 1, pw = (c.d.OW() + 2 - 3) / 2 + 1;
+    DIC_TRY(split_bf16x3(X, (long long)B * ph * pw * 64, Xp[0], Xp[1], Xp[2], st));
+  }
+  for (int s = 0; s < 4; ++s)
+    for (int b = 0; b < blocks[s]; ++b) {
+      const RnConv& c1 = pl.convs[ci++];
+      const RnConv& c2 = pl.convs[ci++];
+      const RnConv& c3 = pl.convs[ci++];
+      DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], A, ws, train_bn, st));
+      DIC_TRY(bn_apply_planes(A, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st));
+      DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], Bf, ws, train_bn, st));
+      DIC_TRY(bn_apply_planes(Bf, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn, 1, st));
+      const float* identity = X;
+      if (b == 0) {
+        const RnConv& ds = pl.convs[ci++];
+        DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st));
+        DIC_TRY(bn_apply(Cf, nullptr, Cf, ds.d.M(), ds.d.CO, ws.bn, 0, st));
+        identity = Cf;
+      }
+      DIC_TRY(conv_bn_bf3(P2, c3.d, layers[c3.layer], A, ws, train_bn, st));
+      // out = relu(bn3 + identity): fp32 (next identity) into Bf, planes (next conv input) into P1 (free again)
+      DIC_TRY(bn_apply_planes(A, identity, Bf, P1, c3.d.M(), c3.d.CO, ws.bn, 1, st));
+      std::swap(X, Bf);
+      std::swap(Xp, P1);
+    }
+  return adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, 14, features, st);
 }
 
 }  // namespace dic
@@ -263,13 +321,14 @@ int dic_resnet_num_layers(const int* blocks) {
   return n;
 }
 
-size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks) {
+size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mode) {
   bool ov;
-  return rn_carve(nullptr, 0, resnet_plan(B, H, W, blocks), &ov).bytes;
+  return rn_carve(nullptr, 0, resnet_plan(B, H, W, blocks), mode, &ov).bytes;
 }
 
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
-                   int H, int W, int train_bn, float* features, void* workspace, size_t workspace_bytes, void* stream) {
+                   int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
+                   void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DIC_REQUIRE(layers && blocks && imgs_nchw && features && workspace, "resnet_fwd: null pointer");
   DIC_REQUIRE(n_layers == dic_resnet_num_layers(blocks), "resnet_fwd: expected %d conv+bn layers, got %d",
@@ -277,8 +336,14 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
   DIC_REQUIRE(B > 0 && H >= 32 && W >= 32, "resnet_fwd: bad input size");
   const RnPlan pl = resnet_plan(B, H, W, blocks);
   bool ov = false;
-  RnWs ws = rn_carve(workspace, workspace_bytes, pl, &ov);
+  DIC_REQUIRE(mode == 0 || mode == 1, "resnet_fwd: mode must be 0 (exact-fp32 MFMA) or 1 (bf16x3 split MFMA)");
+  RnWs ws = rn_carve(workspace, workspace_bytes, pl, mode, &ov);
   DIC_REQUIRE(!ov, "resnet_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+  if (mode == 1) {
+    for (int i = 1; i < n_layers; ++i)
+      DIC_REQUIRE(layers[i].w_hi && layers[i].w_mid && layers[i].w_lo, "resnet_fwd: bf16x3 mode needs split weights");
+    return resnet_fwd_bf3(layers, blocks, imgs_nchw, B, train_bn, features, pl, ws, st);
+  }
 
   size_t ci = 0;
   float *X = ws.act[0], *A = ws.act[1], *Bf = ws.act[2], *Cf = ws.act[3];

@@ -78,6 +78,9 @@ GemmOperand op_gather(const float* x, const ConvGeom& g);
 GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
 GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
 void gemm_force_v1(int on);
+int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st);
+void gemm_profile_mark_begin(hipStream_t st, double flops, int key);
+void gemm_profile_mark_end(hipStream_t st);
 int gemm_profile_begin();
 int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
 GemmEpilogue ep_store(float* C, long long ldc, const float* bias = nullptr, int act = ACT_NONE);

@@ -689,6 +689,20 @@ static hipEvent_t prof_event() {
   return e;
 }
 
+// hooks for contraction launches that do not go through gemm_launch (gemm_bf3.hip)
+static ProfRec g_open_rec{};
+void gemm_profile_mark_begin(hipStream_t st, double flops, int key) {
+  if (!g_prof_on) return;
+  g_open_rec.e0 = prof_event(); g_open_rec.e1 = prof_event();
+  g_open_rec.flops = flops; g_open_rec.key = key;
+  (void)hipEventRecord(g_open_rec.e0, st);
+}
+void gemm_profile_mark_end(hipStream_t st) {
+  if (!g_prof_on) return;
+  (void)hipEventRecord(g_open_rec.e1, st);
+  g_prof_recs.push_back(g_open_rec);
+}
+
 int gemm_profile_begin() {
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
   g_prof_recs.clear();
@@ -794,6 +808,12 @@ static int launch_tile(const GemmParams& p, hipStream_t st) {
 #undef DIC_GEMM_CASE
   set_last_error("gemm: unsupported operand kinds A=%d B=%d", a, b);
   return DIC_ERR_UNSUPPORTED;
+}
+
+int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st) {
+  hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(256), 0, st, p);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
 }
 
 int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {

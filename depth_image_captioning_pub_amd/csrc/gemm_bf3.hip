@@ -1,0 +1,326 @@
+// fp32-accurate contraction on the bf16 matrix cores ("bf16x3"): every fp32 operand is stored as three bf16
+// planes hi + mid + lo (an EXACT decomposition: 3 x 8 significand bits = fp32's 24), and a product a*b is formed
+// as the six bf16 x bf16 products  ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh,  each exact in fp32 and
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms (am*bl, al*bm, al*bl) are <= 2^-24 |ab|,
+// i.e. one fp32 unit round-off, so the result carries fp32-level error (checked against fp64 in the tests) at
+// 6 MFMAs x 32 cycles per K=16 versus 8 x 64 cycles for the exact-fp32 MFMA: 2.67x the matrix-core rate.
+//
+// Kernel structure = gemm_dma_kernel (gemm.hip): 64x64 tile, 4 waves, LDS-DMA staging with source-side swizzle,
+// 2-stage ring, inline-asm fragment reads with counted lgkmcnt, DMA issue in the MFMA shadow.
+#include "conv.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace dic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BK3 = 32;          // K tile in elements (64 B per plane row)
+
+__device__ __attribute__((aligned(256))) const unsigned short g_zero_line16[128] = {0};
+
+__global__ void __launch_bounds__(256) split_bf16x3_kernel(const float* __restrict__ x, long long n,
+                                                            unsigned short* __restrict__ hi,
+                                                            unsigned short* __restrict__ mid,
+                                                            unsigned short* __restrict__ lo) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    unsigned short h, m, l;
+    split3_bf16(x[i], h, m, l);
+    hi[i] = h; mid[i] = m; lo[i] = l;
+  }
+}
+
+struct Bf3Operand {
+  const unsigned short* p[3];   // hi, mid, lo planes, element (i,k) at p[.][i*ld + k]  (or NHWC image for im2col)
+  long long ld;
+  int kind;                     // OPK_ROWK or OPK_IM2COL
+  ConvGeom g;
+};
+
+struct Bf3Params {
+  int M, N, K;
+  Bf3Operand A, B;
+  GemmEpilogue ep;
+  int mtiles, ntiles;
+  int tail_first_block, tail_first_tile, tail_split;   // remainder-tile K split, as in gemm.hip
+  float* tail_ws;
+};
+
+// One operand's DMA bookkeeping: wave w fills rows [16w,16w+16) of each of the three plane images per K tile.
+template <int KIND>
+struct Bf3Loader {
+  const unsigned short* p[3];
+  int K, C, KW, W;
+  long long lane_off;     // elements
+  unsigned tapmask;
+  bool valid;
+  int kchunk;
+
+  __device__ __forceinline__ void init(const Bf3Operand& op, int r0, int R, int K_) {
+    p[0] = op.p[0]; p[1] = op.p[1]; p[2] = op.p[2];
+    K = K_; C = op.g.C; KW = op.g.KW; W = op.g.W;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = w * 16 + (lane >> 2);
+    const int gr = r0 + row;
+    valid = gr < R;
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    kchunk = chunk * 8;
+    tapmask = 0u;
+    if constexpr (KIND == OPK_ROWK) {
+      lane_off = (long long)gr * op.ld + chunk * 8;
+    } else {
+      const ConvGeom& g = op.g;
+      const int ohw = g.OH * g.OW;
+      const int img = gr / ohw, rem = gr - img * ohw;
+      const int oh = rem / g.OW, ow = rem - oh * g.OW;
+      const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+      lane_off = ((long long)img * g.H + ih0) * g.W * g.C + (long long)iw0 * g.C + chunk * 8;
+      unsigned m = 0u;
+      for (int kh = 0; kh < g.KH; ++kh)
+        for (int kw = 0; kw < g.KW; ++kw)
+          if ((unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W) m |= 1u << (kh * g.KW + kw);
+      tapmask = valid ? m : 0u;
+    }
+  }
+
+  // img: this operand's [3][64][32] bf16 image of one stage
+  __device__ __forceinline__ void issue(int k0, unsigned short* img) const {
+    const int w = threadIdx.x >> 6;
+    int tap = 0;
+    long long uni = k0;
+    if constexpr (KIND == OPK_IM2COL) {
+      tap = k0 / C;
+      const int c0 = k0 - tap * C;
+      const int kh = tap / KW, kw = tap - kh * KW;
+      uni = ((long long)kh * W + kw) * C + c0;
+    }
+    bool ok;
+    if constexpr (KIND == OPK_ROWK) ok = valid && (k0 + kchunk < K);
+    else ok = (tapmask >> tap) & 1u;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned short* src = ok ? p[pl] + lane_off + uni : g_zero_line16;
+      unsigned short* dst = img + pl * 64 * BK3 + (w * 16) * BK3;       // wave-uniform 1-KiB block
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
+};
+
+__device__ __forceinline__ float bf3_finalize(const GemmEpilogue& ep, int m, int n, float v) {
+  if (ep.bias) v += ep.bias[n];
+  if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
+  ep.C[(long long)m * ep.ldc + n] = v;
+  return v;
+}
+
+template <int AK, int NSTAGE>
+__global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
+  constexpr int PLANE = 64 * BK3;                 // elements per plane image
+  constexpr int OPER = 3 * PLANE;                 // per operand
+  constexpr int STAGE = 2 * OPER;                 // A + B
+  __shared__ __align__(1024) unsigned short smem[NSTAGE * STAGE];      // 24 KiB per stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (p.K + BK3 - 1) / BK3;
+  int t, kt0 = 0, kt1 = nk, tail_slot = -1;
+  if ((int)blockIdx.x < p.tail_first_block) {
+    t = xcd_remap(blockIdx.x, p.tail_first_block);
+  } else {
+    const int q = (int)blockIdx.x - p.tail_first_block;
+    const int piece = q % p.tail_split;
+    t = p.tail_first_tile + q / p.tail_split;
+    const int per = (nk + p.tail_split - 1) / p.tail_split;
+    kt0 = piece * per;
+    kt1 = min(nk, kt0 + per);
+    tail_slot = q;
+  }
+  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+
+  Bf3Loader<AK> la;
+  Bf3Loader<OPK_ROWK> lbld;
+  la.init(p.A, tm * 64, p.M, p.K);
+  lbld.init(p.B, tn * 64, p.N, p.K);
+  const int nkt = max(kt1 - kt0, 0);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nkt) {
+      la.issue((kt0 + s0) * BK3, smem + s0 * STAGE);
+      lbld.issue((kt0 + s0) * BK3, smem + s0 * STAGE + OPER);
+    }
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  // byte offsets of this lane's two k-step chunks inside a plane image (row-major 64 B rows, swizzled position)
+  const unsigned offA = (unsigned)((wm * 32 + i31) * 64), offB = (unsigned)((wn * 32 + i31) * 64);
+  const unsigned pos0 = (unsigned)(((0 + h) ^ key) * 16), pos1 = (unsigned)(((2 + h) ^ key) * 16);
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+
+  for (int it = 0; it < nkt; ++it) {
+    // tile `it` has landed when at most the (NSTAGE-2) younger tiles' 6 DMA instructions each are outstanding
+    if (NSTAGE == 2 || it + NSTAGE - 2 >= nkt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = it + NSTAGE - 1 < nkt;
+    unsigned short* nx = smem + ((it + NSTAGE - 1) % NSTAGE) * STAGE;
+    const unsigned sb = sbase0 + (unsigned)((it % NSTAGE) * STAGE) * 2u;
+    const unsigned a0 = sb + offA, b0 = sb + (unsigned)OPER * 2u + offB;
+    constexpr unsigned PB = PLANE * 2;            // plane stride in bytes
+    u32x4 ah0, am0, al0, bh0, bm0, bl0, ah1, am1, al1, bh1, bm1, bl1;
+    asm volatile(
+        "ds_read_b128 %0, %12\n\t"
+        "ds_read_b128 %3, %14\n\t"
+        "ds_read_b128 %1, %12 offset:%c16\n\t"
+        "ds_read_b128 %4, %14 offset:%c16\n\t"
+        "ds_read_b128 %2, %12 offset:%c17\n\t"
+        "ds_read_b128 %5, %14 offset:%c17\n\t"
+        "ds_read_b128 %6, %13\n\t"
+        "ds_read_b128 %9, %15\n\t"
+        "ds_read_b128 %7, %13 offset:%c16\n\t"
+        "ds_read_b128 %10, %15 offset:%c16\n\t"
+        "ds_read_b128 %8, %13 offset:%c17\n\t"
+        "ds_read_b128 %11, %15 offset:%c17\n\t"
+        "s_waitcnt lgkmcnt(6)"
+        : "=&v"(ah0), "=&v"(am0), "=&v"(al0), "=&v"(bh0), "=&v"(bm0), "=&v"(bl0), "=&v"(ah1), "=&v"(am1), "=&v"(al1),
+          "=&v"(bh1), "=&v"(bm1), "=&v"(bl1)
+        : "v"(a0 + pos0), "v"(a0 + pos1), "v"(b0 + pos0), "v"(b0 + pos1), "i"(PB), "i"(2 * PB)
+        : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#define DIC_BF3_MFMA(A_, B_) \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), acc, 0, 0, 0);
+    // small terms first
+    DIC_BF3_MFMA(al0, bh0) DIC_BF3_MFMA(ah0, bl0) DIC_BF3_MFMA(am0, bm0)
+    if (more) la.issue((kt0 + it + NSTAGE - 1) * BK3, nx);
+    DIC_BF3_MFMA(am0, bh0) DIC_BF3_MFMA(ah0, bm0) DIC_BF3_MFMA(ah0, bh0)
+    if (more) lbld.issue((kt0 + it + NSTAGE - 1) * BK3, nx + OPER);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah1), "+v"(am1), "+v"(al1), "+v"(bh1), "+v"(bm1), "+v"(bl1)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_BF3_MFMA(al1, bh1) DIC_BF3_MFMA(ah1, bl1) DIC_BF3_MFMA(am1, bm1)
+    DIC_BF3_MFMA(am1, bh1) DIC_BF3_MFMA(ah1, bm1) DIC_BF3_MFMA(ah1, bh1)
+#undef DIC_BF3_MFMA
+  }
+  __syncthreads();
+  if (tail_slot >= 0) {     // raw partial of this K slice, tile-local [64][64] layout (finished by tail_fixup_kernel)
+    float* dst = p.tail_ws + (long long)tail_slot * 64 * 64;
+    const int nl = wn * 32 + (lane & 31), ml = wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(ml + (r & 3) + 8 * (r >> 2)) * 64 + nl] = acc[r];
+    return;
+  }
+
+  // epilogue (C/D map identical to the f32 MFMA): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* sred = reinterpret_cast<float*>(smem);
+  const int n = tn * 64 + wn * 32 + i31;
+  const int m0 = tm * 64 + wm * 32 + 4 * h;
+  float cs = 0.f, cs2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2);
+    if (m < p.M && n < p.N) {
+      const float v = bf3_finalize(p.ep, m, n, acc[r]);
+      cs += v; cs2 += v * v;
+    }
+  }
+  if (p.ep.stats) {
+    cs += __shfl_xor(cs, 32, 64);
+    cs2 += __shfl_xor(cs2, 32, 64);
+    if (wm == 0 && lane < 32) { sred[wn * 32 + lane] = cs; sred[64 + wn * 32 + lane] = cs2; }
+    __syncthreads();
+    if (wm == 1 && lane < 32 && n < p.N) {
+      p.ep.stats[((long long)tm * 2 + 0) * p.N + n] = cs + sred[wn * 32 + lane];
+      p.ep.stats[((long long)tm * 2 + 1) * p.N + n] = cs2 + sred[64 + wn * 32 + lane];
+    }
+  }
+}
+
+}  // namespace dic
+
+namespace dic {
+
+static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws) {
+  p.mtiles = ceil_div(p.M, 64); p.ntiles = ceil_div(p.N, 64);
+  const int T = p.mtiles * p.ntiles, nk = ceil_div(p.K, BK3);
+  int total = T;
+  p.tail_first_block = T; p.tail_first_tile = 0; p.tail_split = 1; p.tail_ws = nullptr;
+  int tail_tiles = 0;
+  if (tail_ws) {
+    const int r = T % 256;
+    int sp = r > 0 ? 256 / r : 0;
+    sp = std::min(sp, std::min(nk / 2, 16));
+    if (r > 0 && r <= 128 && sp >= 2 && T < 7 * 256) {
+      tail_tiles = r; p.tail_first_tile = T - r; p.tail_first_block = T - r; p.tail_split = sp; p.tail_ws = tail_ws;
+      total = (T - r) + r * sp;
+    }
+  }
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10);
+  if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_IM2COL, 2>), dim3(total), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 2>), dim3(total), dim3(256), 0, st, p);
+  DIC_LAUNCH_CHECK();
+  gemm_profile_mark_end(st);
+  if (tail_tiles > 0) {
+    GemmParams g{};
+    g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.ep.alpha = 1.0f; g.mtiles = p.mtiles; g.ntiles = p.ntiles;
+    g.tail_first_tile = p.tail_first_tile; g.tail_split = p.tail_split; g.tail_ws = p.tail_ws;
+    DIC_TRY(gemm_launch_tail_fixup(g, tail_tiles, st));
+  }
+  return DIC_OK;
+}
+
+// y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
+int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
+                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st) {
+  DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
+  Bf3Params p{};
+  p.M = d.M(); p.N = d.CO; p.K = d.K();
+  for (int i = 0; i < 3; ++i) { p.A.p[i] = x_planes[i]; p.B.p[i] = w_planes[i]; }
+  p.A.kind = (d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) ? OPK_ROWK : OPK_IM2COL;
+  p.A.ld = d.C; p.A.g = d.geom();
+  p.B.kind = OPK_ROWK; p.B.ld = d.K();
+  p.ep = ep_store(y, d.CO, nullptr, ACT_NONE);
+  p.ep.stats = bn_partial;
+  if (mtiles_out) *mtiles_out = ceil_div(p.M, 64);
+  return launch_bf3(p, st, tail_ws);
+}
+
+int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st) {
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, st, x, n, hi, mid, lo);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_split_bf16x3(const float* x, long long n, uint16_t* hi, uint16_t* mid, uint16_t* lo, void* stream) {
+  DIC_REQUIRE(x && hi && mid && lo && n > 0, "split_bf16x3: bad arguments");
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+  (void)blocks;
+  return split_bf16x3(x, n, hi, mid, lo, (hipStream_t)stream);
+}
+
+int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
+                    long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
+                    float* C, long long ldc, const float* bias, void* stream) {
+  DIC_REQUIRE(a_hi && a_mid && a_lo && b_hi && b_mid && b_lo && C, "gemm_bf16x3: null pointer");
+  DIC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16x3: K, lda, ldb %% 8");
+  Bf3Params p{};
+  p.M = M; p.N = N; p.K = K;
+  p.A.p[0] = a_hi; p.A.p[1] = a_mid; p.A.p[2] = a_lo; p.A.ld = lda; p.A.kind = OPK_ROWK;
+  p.B.p[0] = b_hi; p.B.p[1] = b_mid; p.B.p[2] = b_lo; p.B.ld = ldb; p.B.kind = OPK_ROWK;
+  p.ep = ep_store(C, ldc, bias, ACT_NONE);
+  return launch_bf3(p, (hipStream_t)stream, nullptr);
+}
+
+}  // extern "C"

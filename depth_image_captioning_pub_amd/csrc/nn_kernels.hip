@@ -112,6 +112,45 @@ int bn_apply(const float* x, const float* residual, float* y, long long rows, in
   return DIC_OK;
 }
 
+// y = act(x*scale + shift (+ residual)) written as three bf16 planes (operand format of the bf16x3 convolution,
+// gemm_bf3.hip) and optionally also as fp32 (block outputs are the next block's identity).
+__global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                               float* __restrict__ y, unsigned short* __restrict__ hi,
+                                                               unsigned short* __restrict__ mid,
+                                                               unsigned short* __restrict__ lo, long long n4, int C4,
+                                                               BnBuf bn, int relu) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)(i % C4) * 4;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 s = *reinterpret_cast<const float4*>(bn.scale + c);
+    const float4 t = *reinterpret_cast<const float4*>(bn.shift + c);
+    v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (y) reinterpret_cast<float4*>(y)[i] = v;
+    unsigned short h[4], m[4], l[4];
+    split3_bf16(v.x, h[0], m[0], l[0]); split3_bf16(v.y, h[1], m[1], l[1]);
+    split3_bf16(v.z, h[2], m[2], l[2]); split3_bf16(v.w, h[3], m[3], l[3]);
+    reinterpret_cast<uint2*>(hi)[i] = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    reinterpret_cast<uint2*>(mid)[i] = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    reinterpret_cast<uint2*>(lo)[i] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+
+int bn_apply_planes(const float* x, const float* residual, float* y, unsigned short* const planes[3], long long rows,
+                    int C, BnBuf bn, int relu, hipStream_t st) {
+  DIC_REQUIRE(C % 4 == 0, "bn_apply_planes: C %% 4");
+  const long long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, y, planes[0], planes[1],
+                     planes[2], n4, C / 4, bn, relu);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // fused BN + ReLU + max pooling (records the argmax position for the backward pass)
 // ------------------------------------------------------------------------------------------

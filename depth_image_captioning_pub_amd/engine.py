@@ -100,7 +100,7 @@ class CaptionTrainer:
                  depth_init: Optional[Dict[str, torch.Tensor]] = None,
                  depth_state: Optional[Dict[str, torch.Tensor]] = None,
                  resnet_init: Optional[Dict[str, torch.Tensor]] = None,
-                 process_group=None):
+                 process_group=None, conv_mode: str = "fp32"):
         if not torch.cuda.is_available():
             raise DicError("CaptionTrainer needs a GPU: the product path has no CPU fallback")
         self.device = torch.device(device)
@@ -124,7 +124,7 @@ class CaptionTrainer:
         self.enc_span = self.flat.span(["depth_encoder." + k for k in self.enc_names])
         self.enc_state = {k: v.to(self.device).contiguous() for k, v in depth_state.items()}
         self.rn_w = {k: v.to(self.device).contiguous() for k, v in rn.items()}
-        self.resnet = native.ResNetRunner(self.rn_w, resnet_layers)
+        self.resnet = native.ResNetRunner(self.rn_w, resnet_layers, conv_mode=conv_mode)
         self.step_count = 0
         self.rng_offset = 0
         self.seed = seed

@@ -266,16 +266,24 @@ def depth_encoder_backward(tape: DepthTape, d_features: torch.Tensor, grads: Opt
 # RGB encoder (dic_resnet_fwd)
 # ---------------------------------------------------------------------------------------------
 class ConvBnLayer(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f in ("w", "gamma", "beta", "running_mean", "running_var")]
+    _fields_ = [(f, C.c_void_p) for f in ("w", "gamma", "beta", "running_mean", "running_var", "w_hi", "w_mid", "w_lo")]
+
+
+CONV_MODES = {"fp32": 0, "bf16x3": 1}
 
 
 class ResNetRunner:
     """Holds the OHWI copies of the (frozen) ResNet conv weights and the layer table for dic_resnet_fwd.
     `tensors` is keyed like CNNEncoder_Atten.state_dict() ('backbone.0.weight', 'backbone.1.running_mean', ...)."""
 
-    def __init__(self, tensors: Dict[str, torch.Tensor], layers: Sequence[int] = (3, 8, 36, 3)):
+    def __init__(self, tensors: Dict[str, torch.Tensor], layers: Sequence[int] = (3, 8, 36, 3), conv_mode: str = "fp32"):
+        """conv_mode "fp32": exact-fp32 MFMA convolutions; "bf16x3": fp32-accurate split-bf16 convolutions
+        (each fp32 weight/activation = hi+mid+lo bf16 exactly, 6 products; csrc/gemm_bf3.hip)."""
         from .synthetic import resnet152_spec
         lib = _lib.load()
+        if conv_mode not in CONV_MODES:
+            raise _lib.DicError(f"conv_mode must be one of {list(CONV_MODES)}")
+        self.mode = CONV_MODES[conv_mode]
         self.blocks = (C.c_int * 4)(*[int(x) for x in layers])
         self.spec = resnet152_spec(layers)
         self.n_layers = len(self.spec)
@@ -293,6 +301,12 @@ class ResNetRunner:
             ent = self.table[i]
             ent.w = w_ohwi.data_ptr()
             tens = [w, w_ohwi]
+            if self.mode == 1 and i > 0:             # the C_in = 3 stem stays on the exact-fp32 gather kernel
+                planes = [torch.empty(w_ohwi.numel(), dtype=torch.int16, device=w_ohwi.device) for _ in range(3)]
+                check(lib.dic_split_bf16x3(ptr(w_ohwi), C.c_longlong(w_ohwi.numel()), ptr(planes[0]), ptr(planes[1]),
+                                           ptr(planes[2]), stream_ptr()), "dic_split_bf16x3")
+                ent.w_hi, ent.w_mid, ent.w_lo = (pl.data_ptr() for pl in planes)
+                tens += planes
             for field, name in (("gamma", "weight"), ("beta", "bias"), ("running_mean", "running_mean"),
                                 ("running_var", "running_var")):
                 t = tensors[bn + name]
@@ -310,12 +324,13 @@ class ResNetRunner:
         if c != 3:
             raise _lib.DicError("images must be [B,3,H,W]")
         lib.dic_resnet_workspace_bytes.restype = C.c_size_t
-        need = lib.dic_resnet_workspace_bytes(B, H, W, self.blocks)
+        need = lib.dic_resnet_workspace_bytes(B, H, W, self.blocks, self.mode)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         if out is None:
             out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=x.device)
-        rc = lib.dic_resnet_fwd(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, ptr(out),
+        rc = lib.dic_resnet_fwd(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, self.mode,
+                                ptr(out),
                                 ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
         check(rc, "dic_resnet_fwd")
         return out

@@ -170,16 +170,27 @@ typedef struct dic_conv_bn_layer {
   const float* w;                 /* [CO][KH][KW][CI] */
   const float *gamma, *beta;
   float *running_mean, *running_var;
+  const uint16_t *w_hi, *w_mid, *w_lo;   /* mode 1 only: dic_split_bf16x3 of w (same OHWI order); NULL otherwise */
 } dic_conv_bn_layer;
 
 int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream);
 int dic_resnet_num_layers(const int* blocks);
-size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks);
+size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mode);
 /* imgs [B,3,H,W] NCHW -> features [B,196,2048].  train_bn=1 reproduces quirk Q1 of the reference
  * (encoder.train() at depth_train.py:161: batch statistics + running-stat updates in the frozen net);
- * train_bn=0 is encoder.eval() (depth_train.py:242). */
+ * train_bn=0 is encoder.eval() (depth_train.py:242).
+ * mode 0: exact-fp32 MFMA convolutions; mode 1: fp32-accurate bf16x3 split convolutions (csrc/gemm_bf3.hip; every
+ * layer but the C_in=3 stem), same results to fp32 rounding level, ~1.4x the conv throughput at batch 64. */
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
-                   int H, int W, int train_bn, float* features, void* workspace, size_t workspace_bytes, void* stream);
+                   int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---- fp32-accurate contraction on the bf16 matrix cores (csrc/gemm_bf3.hip): operands are stored as three bf16
+ *      planes hi+mid+lo (exact split of fp32), C = A*B^T from 6 exact bf16 products per k accumulated in fp32. */
+int dic_split_bf16x3(const float* x, long long n, uint16_t* hi, uint16_t* mid, uint16_t* lo, void* stream);
+int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
+                    long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
+                    float* C, long long ldc, const float* bias, void* stream);
 
 /* ---- host data path on the device: the tensor work of util.collate_func_for_dep
  *      (Captioning_models/util.py:13-17,100-101), DPT_Depthestimator.standardize_depth_map
@@ -198,7 +209,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
 
 /* ---- measurement aid (bench.py roofline): per-launch HIP events around every MFMA contraction launch,
  *      recorded on the launch stream; dic_profile_end synchronises and returns, per kernel instantiation
- *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind), total milliseconds, algorithmic FLOPs and launches. */
+ *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind; 2000 + 10*A_kind = bf16x3 kernel), total milliseconds, algorithmic FLOPs and launches. */
 /* benchmarking aid: 1 = run every contraction on the register-staged kernel (v1) instead of the LDS-DMA one */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);

@@ -81,9 +81,10 @@ def test_depth_encoder_eval_mode(lib):
         assert torch.equal(st_dev[k].cpu(), st[k]), "eval mode must not touch the running statistics"
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("layers,B,size,train", [((1, 1, 1, 1), 2, 64, True), ((1, 1, 1, 1), 2, 64, False),
                                                   ((2, 1, 2, 1), 3, 96, True)])
-def test_resnet_small_stacks(lib, layers, B, size, train):
+def test_resnet_small_stacks(lib, layers, B, size, train, mode):
     w = syn.resnet152_weights(seed=125, layers=layers)
     g = torch.Generator().manual_seed(7)
     for k in list(w):
@@ -97,7 +98,7 @@ def test_resnet_small_stacks(lib, layers, B, size, train):
     w_ref = {k: v.clone() for k, v in w.items()}
     y_ref = orc.resnet152_features(w_ref, x, train_bn=train, layers=layers)
     wd = _dev(w)
-    runner = native.ResNetRunner(wd, layers)
+    runner = native.ResNetRunner(wd, layers, conv_mode=mode)
     y = runner.forward(x.to(DEV), train_bn=train)
     _close("features", y, y_ref, 5e-4)
     for k in w:
@@ -108,7 +109,8 @@ def test_resnet_small_stacks(lib, layers, B, size, train):
                 assert torch.equal(wd[k].cpu(), w[k])
 
 
-def test_resnet152_full_depth(lib):
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_resnet152_full_depth(lib, mode):
     """All 155 conv+BN layers at 224x224 (B=2), batch-statistics mode (quirk Q1).  fp32 rounding is amplified by
     152 layers of batch-statistics BatchNorm over a 2-image batch, so the yardstick is an fp64 evaluation of the
     oracle: the GPU result must sit inside the same error envelope as the fp32 CPU path (<= 4x its error)."""
@@ -116,7 +118,7 @@ def test_resnet152_full_depth(lib):
     x = syn.rgb_images(2, seed=123)
     y_ref = orc.resnet152_features({k: v.clone() for k, v in w.items()}, x, train_bn=True)
     y64 = orc.resnet152_features({k: v.double() for k, v in w.items()}, x.double(), train_bn=True)
-    runner = native.ResNetRunner(_dev(w))
+    runner = native.ResNetRunner(_dev(w), conv_mode=mode)
     y = runner.forward(x.to(DEV), train_bn=True)
     assert y.shape == (2, 196, 2048)
     y4 = y.reshape(2, 7, 2, 7, 2, 2048)
@@ -124,6 +126,6 @@ def test_resnet152_full_depth(lib):
     scale = float(y64.abs().max())
     err_cpu32 = float((y_ref.double() - y64).abs().max()) / scale
     err_gpu = float((y.cpu().double() - y64).abs().max()) / scale
-    print(f"ResNet-152 fp32 error vs fp64: CPU oracle {err_cpu32:.2e}, HIP {err_gpu:.2e}")
+    print(f"ResNet-152 error vs fp64: CPU fp32 oracle {err_cpu32:.2e}, HIP[{mode}] {err_gpu:.2e}")
     assert err_gpu <= max(4.0 * err_cpu32, 5e-4), (err_gpu, err_cpu32)
     _close("features", y, y_ref, 5e-3)

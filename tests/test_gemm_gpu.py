@@ -149,3 +149,31 @@ def test_conv_tail_split_matches_plain(lib, B, H, C_in, CO, k):
     assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-3)
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.permute(0, 3, 1, 2).cpu(), bias.cpu(), padding=k // 2)
     _close(outs[1][0], ref.permute(0, 2, 3, 1), 2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1000, 130, 520), (777, 64, 2304), (64, 512, 32)])
+def test_gemm_bf16x3_is_fp32_accurate(lib, M, N, K):
+    """Split-bf16 contraction (csrc/gemm_bf3.hip): the hi/mid/lo split is exact and the result is at least as close to
+    an fp64 evaluation as the exact-fp32 MFMA kernel (bound: 1.5x its error + 1 ulp-level slack)."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) * torch.logspace(-3, 3, N).unsqueeze(1)      # wide dynamic range across rows
+    ref = A.double() @ B.double().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+
+    def split(x):
+        hi, mid, lo = (torch.empty(x.numel(), dtype=torch.int16, device=DEV) for _ in range(3))
+        check(lib.dic_split_bf16x3(ptr(x), C.c_longlong(x.numel()), ptr(hi), ptr(mid), ptr(lo), stream_ptr()), "split")
+        rec = (hi.view(torch.bfloat16).float() + mid.view(torch.bfloat16).float()) + lo.view(torch.bfloat16).float()
+        assert torch.equal(rec.view_as(x), x), "hi + mid + lo must reproduce the fp32 value exactly"
+        return hi, mid, lo
+
+    a, b = split(Ad), split(Bd)
+    C3 = torch.full((M, N), float("nan"), device=DEV)
+    check(lib.dic_gemm_bf16x3(M, N, K, ptr(a[0]), ptr(a[1]), ptr(a[2]), C.c_longlong(K), ptr(b[0]), ptr(b[1]), ptr(b[2]),
+                              C.c_longlong(K), ptr(C3), C.c_longlong(N), None, stream_ptr()), "dic_gemm_bf16x3")
+    C1 = _gemm(lib, Ad, Bd, 0, 0, M, N, K)
+    col = ref.abs().max(dim=0).values + 1e-30                                        # per-column scale
+    e3 = float(((C3.cpu().double() - ref).abs() / col).max())
+    e1 = float(((C1.cpu().double() - ref).abs() / col).max())
+    assert e3 <= 1.5 * e1 + 2e-7, (e3, e1)
