@@ -162,6 +162,8 @@ def main():
     from depth_image_captioning_pub_amd import synthetic as syn
     from depth_image_captioning_pub_amd.engine import CaptionTrainer
 
+    if os.environ.get("DIC_BF3_POLICY"):
+        _lib.load().dic_debug_force_staged_gemm(int(os.environ["DIC_BF3_POLICY"]))
     B = args.batch
     trainer = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=args.conv_mode)
     imgs = syn.rgb_images(B, seed=123 + rank).to(dev)

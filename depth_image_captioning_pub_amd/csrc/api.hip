@@ -34,7 +34,11 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
   return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile, tail_ws);
 }
 
-int dic_debug_force_staged_gemm(int on) { gemm_force_v1(on); return 0; }
+int dic_debug_force_staged_gemm(int on) {
+  if (on == 11 || on == 21 || on == 22 || on == 20 || on == 31) gemm_bf3_force_tile(on == 20 ? 0 : on);
+  else gemm_force_v1(on);
+  return 0;
+}
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
   DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");

@@ -78,6 +78,7 @@ GemmOperand op_gather(const float* x, const ConvGeom& g);
 GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
 GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
 void gemm_force_v1(int on);
+void gemm_bf3_force_tile(int code);
 int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st);
 void gemm_profile_mark_begin(hipStream_t st, double flops, int key);
 void gemm_profile_mark_end(hipStream_t st);

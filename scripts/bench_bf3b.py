@@ -1,0 +1,33 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from depth_image_captioning_pub_amd import _lib
+from depth_image_captioning_pub_amd._lib import ptr, stream_ptr, check
+lib = _lib.load(); DEV = "cuda:0"
+def split(x):
+    n = x.numel(); hi = torch.empty(n, dtype=torch.int16, device=DEV); mid = torch.empty_like(hi); lo = torch.empty_like(hi)
+    check(lib.dic_split_bf16x3(ptr(x), C.c_longlong(n), ptr(hi), ptr(mid), ptr(lo), stream_ptr())); return hi, mid, lo
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+shapes = [(200704, 64, 256), (200704, 64, 576), (200704, 256, 64), (50176, 128, 512), (50176, 128, 1152), (50176, 512, 128),
+          (12544, 256, 1024), (12544, 256, 2304), (12544, 1024, 256), (3136, 512, 2048), (3136, 512, 4608), (3136, 2048, 512), (4096, 4096, 4096)]
+for (M, N, K) in shapes:
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=g).to(DEV); B = torch.randn(N, K, generator=g).to(DEV)
+    a = split(A); b = split(B); Cb = torch.empty(M, N, device=DEV)
+    out = []
+    ref = None
+    for code in (11, 21, 22):
+        lib.dic_debug_force_staged_gemm(code)
+        f = lambda: check(lib.dic_gemm_bf16x3(M, N, K, ptr(a[0]), ptr(a[1]), ptr(a[2]), C.c_longlong(K), ptr(b[0]), ptr(b[1]), ptr(b[2]), C.c_longlong(K), ptr(Cb), C.c_longlong(N), None, stream_ptr()))
+        us = timeit(f, 10)
+        if ref is None: ref = Cb.clone()
+        ok = bool(torch.allclose(Cb, ref, rtol=1e-4, atol=1e-3))
+        out.append(f"{code}: {us:7.1f}us {2*M*N*K/us/1e6:6.1f}TF{'' if ok else ' MISMATCH'}")
+    print(f"M={M:6d} N={N:5d} K={K:5d} | " + " | ".join(out), flush=True)
