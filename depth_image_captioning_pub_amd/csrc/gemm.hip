@@ -447,12 +447,20 @@ __global__ void __launch_bounds__(256) tail_fixup_kernel(const GemmParams p) {
   float4 v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < p.tail_split; ++s) {
+  // slices in groups of four: 16 independent 16-B loads in flight per thread (fixed summation order)
+  for (int s0 = 0; s0 < p.tail_split; s0 += 4) {
+    float4 x[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4 x = *reinterpret_cast<const float4*>(base + (long long)s * BM * BN + r * BN);
-      v[r].x += x.x; v[r].y += x.y; v[r].z += x.z; v[r].w += x.w;
-    }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        x[u][r] = (s0 + u < p.tail_split)
+                      ? *reinterpret_cast<const float4*>(base + (long long)(s0 + u) * BM * BN + r * BN)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r].x += x[u][r].x; v[r].y += x[u][r].y; v[r].z += x[u][r].z; v[r].w += x[u][r].w; }
   }
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cs2 = cs;
   const int n = tn * BN + c4 * 4;

@@ -295,11 +295,21 @@ namespace dic {
 
 static int g_last_mtiles = 0;   // M tiles of the most recent launch (row count of the BN partial-sum table)
 static int g_bf3_force = 0;     // benchmarking: 11 / 21 / 22 force the 64x64 / 128x64 / 128x128 workgroup tile
-void gemm_bf3_force_tile(int code) { g_bf3_force = code; }
+void gemm_bf3_force_tile(int code);
 
+static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
 template <int AK, int TM, int TN>
 static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
+  if constexpr (TM == 2) {
+    if (g_bf3_stages == 3) { hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 3>), dim3(blocks), dim3(256), 0, st, p); return; }
+  }
   hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 2>), dim3(blocks), dim3(256), 0, st, p);
+}
+
+void gemm_bf3_force_tile(int code) {
+  if (code == 42) { g_bf3_stages = 2; return; }
+  if (code == 43) { g_bf3_stages = 3; return; }
+  g_bf3_force = code;
 }
 
 static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws) {

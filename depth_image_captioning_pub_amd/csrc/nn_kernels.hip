@@ -63,13 +63,75 @@ __global__ void __launch_bounds__(256) bn_finalize_eval_kernel(int C, const floa
   out.invstd[c] = invstd;
 }
 
-size_t bn_finalize_ws_doubles(long long max_mtiles, int C) { return 16; }   // (kept for ABI stability; unused)
+// Two-stage variant for layers with thousands of M tiles and few channels (a C/32-block grid would crawl):
+// stage 1 reduces slices of 256 tiles to fp64 partials red[S][2][C]; stage 2 is the kernel above on those partials.
+constexpr int kBnSliceTiles = 256;
+__global__ void __launch_bounds__(256) bn_stats_slice_kernel(const float* __restrict__ partial, int mtiles, int C,
+                                                              double* __restrict__ red) {
+  __shared__ double s1[8][32], s2[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int t0 = blockIdx.y * kBnSliceTiles, t1 = min(mtiles, t0 + kBnSliceTiles);
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int t = t0 + g; t < t1; t += 8) {
+      a += (double)partial[((long long)t * 2 + 0) * C + c];
+      b += (double)partial[((long long)t * 2 + 1) * C + c];
+    }
+  s1[g][cl] = a; s2[g][cl] = b;
+  __syncthreads();
+  if (g == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { a += s1[i][cl]; b += s2[i][cl]; }
+    red[((long long)blockIdx.y * 2 + 0) * C + c] = a;
+    red[((long long)blockIdx.y * 2 + 1) * C + c] = b;
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_from_slices_kernel(const double* __restrict__ red, int slices,
+                                                                       double count, int C,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta,
+                                                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                       BnBuf out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < slices; ++s) {
+    a += red[((long long)s * 2 + 0) * C + c];
+    b += red[((long long)s * 2 + 1) * C + c];
+  }
+  const double mean = a / count;
+  double var = b / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = 1.0f / sqrtf((float)var + kBnEps);
+  const float sc = gamma[c] * invstd;
+  out.scale[c] = sc;
+  out.shift[c] = beta[c] - (float)mean * sc;
+  out.mean[c] = (float)mean;
+  out.invstd[c] = invstd;
+  if (rmean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
+    rvar[c] = (1.f - kBnMomentum) * rvar[c] + kBnMomentum * (float)unb;
+  }
+}
+
+size_t bn_finalize_ws_doubles(long long max_mtiles, int C) {
+  return (size_t)ceil_div(max_mtiles, kBnSliceTiles) * 2 * (size_t)C + 16;
+}
 
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, BnBuf out, double* red, hipStream_t st) {
-  (void)red;
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partial, mtiles, (double)count,
-                     C, gamma, beta, running_mean, running_var, out);
+  if (mtiles > 512 && red != nullptr) {
+    const int slices = ceil_div(mtiles, kBnSliceTiles);
+    hipLaunchKernelGGL(bn_stats_slice_kernel, dim3(ceil_div(C, 32), slices), dim3(256), 0, st, partial, mtiles, C, red);
+    hipLaunchKernelGGL(bn_finalize_from_slices_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)red,
+                       slices, (double)count, C, gamma, beta, running_mean, running_var, out);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partial, mtiles,
+                       (double)count, C, gamma, beta, running_mean, running_var, out);
+  }
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

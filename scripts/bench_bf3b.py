@@ -15,7 +15,8 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-shapes = [(200704, 64, 256), (200704, 64, 576), (200704, 256, 64), (50176, 128, 512), (50176, 128, 1152), (50176, 512, 128),
+shapes = [(200704, 64, 576), (50176, 128, 1152), (50176, 512, 128), (12544, 256, 2304), (12544, 1024, 256), (3136, 512, 4608), (4096, 4096, 4096), (8192, 8192, 2048)]
+_unused = [(200704, 64, 256), (200704, 64, 576), (200704, 256, 64), (50176, 128, 512), (50176, 128, 1152), (50176, 512, 128),
           (12544, 256, 1024), (12544, 256, 2304), (12544, 1024, 256), (3136, 512, 2048), (3136, 512, 4608), (3136, 2048, 512), (4096, 4096, 4096)]
 for (M, N, K) in shapes:
     g = torch.Generator().manual_seed(1)
@@ -23,11 +24,11 @@ for (M, N, K) in shapes:
     a = split(A); b = split(B); Cb = torch.empty(M, N, device=DEV)
     out = []
     ref = None
-    for code in (11, 21, 22):
-        lib.dic_debug_force_staged_gemm(code)
+    for code, st in ((11, 42), (21, 42), (21, 43), (22, 42), (22, 43)):
+        lib.dic_debug_force_staged_gemm(st); lib.dic_debug_force_staged_gemm(code)
         f = lambda: check(lib.dic_gemm_bf16x3(M, N, K, ptr(a[0]), ptr(a[1]), ptr(a[2]), C.c_longlong(K), ptr(b[0]), ptr(b[1]), ptr(b[2]), C.c_longlong(K), ptr(Cb), C.c_longlong(N), None, stream_ptr()))
         us = timeit(f, 10)
         if ref is None: ref = Cb.clone()
         ok = bool(torch.allclose(Cb, ref, rtol=1e-4, atol=1e-3))
-        out.append(f"{code}: {us:7.1f}us {2*M*N*K/us/1e6:6.1f}TF{'' if ok else ' MISMATCH'}")
+        out.append(f"{code}/{st-40}st: {us:7.1f}us {2*M*N*K/us/1e6:6.1f}TF{'' if ok else ' MISMATCH'}")
     print(f"M={M:6d} N={N:5d} K={K:5d} | " + " | ".join(out), flush=True)
