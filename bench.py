@@ -141,6 +141,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("DIC_DIST_BACKEND", "nccl")       # "gloo" + DIC_SHARE_GPU=1: rehearsal on a 1-GPU box
+    if os.environ.get("DIC_SHARE_GPU"):
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -149,8 +152,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
-                                             device_id=torch.device(dev))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
 
     from depth_image_captioning_pub_amd import build as dic_build, _lib
