@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--conv-mode", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="ResNet convolutions: exact-fp32 MFMA, or the fp32-accurate split-bf16 (hi+mid+lo, 6 products) "
                          "path whose error vs fp64 is <= the exact-fp32 kernel's (tests/test_gemm_gpu.py, test_encoders_gpu.py)")
+    ap.add_argument("--no-alt-mode", action="store_true",
+                    help="skip the short second measurement with the other ResNet convolution mode")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the next batch's frozen ResNet forward with the current step")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -212,6 +214,28 @@ def main():
         trainer.train_step(*step_args)
     ms_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    # ---- same workload with the other convolution arithmetic (short run: 2 warm-up + 5 timed steps) ----
+    alt = None
+    if not args.no_alt_mode:
+        alt_mode = "fp32" if args.conv_mode == "bf16x3" else "bf16x3"
+        del trainer
+        torch.cuda.empty_cache()
+        tr2 = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=alt_mode)
+        for _ in range(2):
+            tr2.train_step(*step_args, **pipe)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            tr2.train_step(*step_args, **pipe)
+        sync()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            e2 = float(t.item())
+        alt = {"resnet_conv_mode": alt_mode, "value": round(world * B * 5 / e2, 2), "unit": "images/s",
+               "ms_per_step": round(e2 / 5 * 1e3, 3), "steps": 5, "warmup": 2}
+        del tr2
     result = None
     if rank == 0:
         top = prof[0]
@@ -246,6 +270,7 @@ def main():
                        "parallelism": f"dp{world}", "resnet_conv_mode": args.conv_mode,
                        "cross_step_resnet_overlap": not args.no_overlap},
             "loss": round(loss_val, 5), "stages_ms": stages, "roofline": roofline, "decoder_roofline": decoder_roofline,
+            "other_conv_mode": alt,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
