@@ -21,11 +21,14 @@ int conv_fwd(const float* x, const ConvDesc& d, const float* w_ohwi, const float
              float* bn_partial, int* mtiles_out, hipStream_t st, int force_tile = 0, float* tail_ws = nullptr);
 int conv_mtiles(const ConvDesc& d, int force_tile = 0);
 
-// fp32-accurate convolution on the bf16 matrix cores (gemm_bf3.hip): activations and weights are given as three
-// bf16 planes (hi, mid, lo) each; output is raw fp32 + the same BN partial sums as conv_fwd (64-row M tiles).
+// fp32-accurate convolution on the bf16 matrix cores (gemm_bf3.hip): activations ([B*H*W rows][C]) and weights
+// ([CO rows][KH*KW*C]) are given as three bf16 planes (hi, mid, lo) each, in the row-pair interleaved layout
+// (plane_offset(..., paired = 1), gemm.h); output is raw fp32 + the same BN partial sums as conv_fwd (64-row M tiles).
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st);
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);
+int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
+                        unsigned short* lo, hipStream_t st);
 
 // dW[CO][KH][KW][C] = sum_m dY[m,co] * patch(m)[kh,kw,c]   (split over M with workspace `ws`)
 int conv_wgrad(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk, float* ws,

@@ -159,7 +159,7 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov
   for (int i = 0; i < 4; ++i) w.act[i] = c.take<float>(pl.max_act);
   if (mode == 1)
     for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) w.planes[i][j] = c.take<unsigned short>(pl.max_act);
+      for (int j = 0; j < 3; ++j) w.planes[i][j] = c.take<unsigned short>(pl.max_act + 2048);   // + one pad row (paired layout)
   w.partial = c.take<float>(pl.max_partial);
   w.red = c.take<double>(pl.max_red);
   w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
@@ -206,7 +206,7 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
     DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
     DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
     const int ph = (c.d.OH() + 2 - 3) / 2 + 1, pw = (c.d.OW() + 2 - 3) / 2 + 1;
-    DIC_TRY(split_bf16x3(X, (long long)B * ph * pw * 64, Xp[0], Xp[1], Xp[2], st));
+    DIC_TRY(split_bf16x3_paired(X, (long long)B * ph * pw, 64, Xp[0], Xp[1], Xp[2], st));
   }
   for (int s = 0; s < 4; ++s)
     for (int b = 0; b < blocks[s]; ++b) {

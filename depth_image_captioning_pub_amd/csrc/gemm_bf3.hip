@@ -32,10 +32,35 @@ __global__ void __launch_bounds__(256) split_bf16x3_kernel(const float* __restri
   }
 }
 
+// Same split, written in the row-pair interleaved layout (plane_offset, gemm.h): 16 threads fill one 128-B line.
+__global__ void __launch_bounds__(256) split_bf16x3_paired_kernel(const float* __restrict__ x, long long rows, int K,
+                                                                   unsigned short* __restrict__ hi,
+                                                                   unsigned short* __restrict__ mid,
+                                                                   unsigned short* __restrict__ lo) {
+  const long long n4 = ((rows + 1) >> 1) * (K / 2);          // float4 slots of the padded plane
+  const int kb = K / 32;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const long long line = i >> 4;
+    const int j = (int)(i & 15);
+    const long long r = (line / kb) * 2 + (j >> 3);
+    const int k = (int)(line % kb) * 32 + (j & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *reinterpret_cast<const float4*>(x + r * K + k);
+    unsigned short h[4], m[4], l[4];
+    split3_bf16(v.x, h[0], m[0], l[0]); split3_bf16(v.y, h[1], m[1], l[1]);
+    split3_bf16(v.z, h[2], m[2], l[2]); split3_bf16(v.w, h[3], m[3], l[3]);
+    reinterpret_cast<uint2*>(hi)[i] = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    reinterpret_cast<uint2*>(mid)[i] = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    reinterpret_cast<uint2*>(lo)[i] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+
 struct Bf3Operand {
   const unsigned short* p[3];   // hi, mid, lo planes, element (i,k) at p[.][i*ld + k]  (or NHWC image for im2col)
   long long ld;
   int kind;                     // OPK_ROWK or OPK_IM2COL
+  int paired;                   // row-pair interleaved storage (see plane_offset): DMA fetches whole 128-B lines
   ConvGeom g;
 };
 
@@ -56,7 +81,8 @@ template <int KIND, int BR>
 struct Bf3Loader {
   static constexpr int NI = BR / 64;
   const unsigned short* p[3];
-  int K, C, KW, W;
+  int K, C, KW, W, paired;
+  int pix0[NI];               // paired im2col: linear input pixel of tap (0,0) (may be negative: masked by tapmask)
   long long lane_off[NI];     // elements
   unsigned tapmask[NI];
   bool valid[NI];
@@ -64,7 +90,7 @@ struct Bf3Loader {
 
   __device__ __forceinline__ void init(const Bf3Operand& op, int r0, int R, int K_) {
     p[0] = op.p[0]; p[1] = op.p[1]; p[2] = op.p[2];
-    K = K_; C = op.g.C; KW = op.g.KW; W = op.g.W;
+    K = K_; C = op.g.C; KW = op.g.KW; W = op.g.W; paired = op.paired;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
@@ -75,7 +101,7 @@ struct Bf3Loader {
       kchunk[n] = chunk * 8;
       tapmask[n] = 0u;
       if constexpr (KIND == OPK_ROWK) {
-        lane_off[n] = (long long)gr * op.ld + chunk * 8;
+        lane_off[n] = op.paired ? plane_offset(gr, chunk * 8, op.ld / 32, 1) : (long long)gr * op.ld + chunk * 8;
       } else {
         const ConvGeom& g = op.g;
         const int ohw = g.OH * g.OW;
@@ -83,6 +109,7 @@ struct Bf3Loader {
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
         const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
         lane_off[n] = ((long long)img * g.H + ih0) * g.W * g.C + (long long)iw0 * g.C + chunk * 8;
+        pix0[n] = (img * g.H + ih0) * g.W + iw0;
         unsigned m = 0u;
         for (int kh = 0; kh < g.KH; ++kh)
           for (int kw = 0; kw < g.KW; ++kw)
@@ -95,22 +122,30 @@ struct Bf3Loader {
   // img: this operand's [3][BR][32] bf16 image of one stage
   __device__ __forceinline__ void issue(int k0, unsigned short* img) const {
     const int w = threadIdx.x >> 6;
-    int tap = 0;
-    long long uni = k0;
+    int tap = 0, dpix = 0;
+    long long uni = paired ? (long long)(k0 >> 5) * 64 : (long long)k0;
     if constexpr (KIND == OPK_IM2COL) {
       tap = k0 / C;
       const int c0 = k0 - tap * C;
       const int kh = tap / KW, kw = tap - kh * KW;
-      uni = ((long long)kh * W + kw) * C + c0;
+      dpix = kh * W + kw;
+      uni = paired ? (long long)(c0 >> 5) * 64 : ((long long)kh * W + kw) * C + c0;
     }
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       bool ok;
       if constexpr (KIND == OPK_ROWK) ok = valid[n] && (k0 + kchunk[n] < K);
       else ok = (tapmask[n] >> tap) & 1u;
+      long long off = lane_off[n] + uni;
+      if constexpr (KIND == OPK_IM2COL) {
+        if (paired) {   // the tap moves the pixel, and with it the half of the 128-B pair line
+          const int pix = pix0[n] + dpix;
+          off = (long long)(pix >> 1) * (C * 2) + ((pix & 1) << 5) + kchunk[n] + uni;
+        }
+      }
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
-        const unsigned short* src = ok ? p[pl] + lane_off[n] + uni : g_zero_line16;
+        const unsigned short* src = ok ? p[pl] + off : g_zero_line16;
         unsigned short* dst = img + pl * BR * BK3 + ((n * 4 + w) * 16) * BK3;       // wave-uniform 1-KiB block
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -124,7 +159,7 @@ __device__ __forceinline__ void bf3_lds_read(u32x4& dst, unsigned addr) {
 }
 
 // Workgroup tile (64*TM) x (64*TN), 4 waves (2x2), each wave TM x TN MFMA tiles of 32x32.
-template <int AK, int TM, int TN, int NSTAGE>
+template <int AK, int TM, int TN, int NSTAGE, int ABL = 0>
 __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, WM = 32 * TM, WN = 32 * TN;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3;      // elements per plane image
@@ -190,6 +225,12 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
       const unsigned a0 = sb + offA, b0 = sb + (unsigned)(AOPER * 2) + offB;
       constexpr unsigned PA = APLANE * 2, PBb = BPLANE * 2;        // plane strides in bytes
       u32x4 ah0, am0, al0, bh0, bm0, bl0, ah1, am1, al1, bh1, bm1, bl1;
+      if constexpr (ABL >= 2) {   // ablation: no LDS reads, operands are loop-variant constants
+        const unsigned c = 0x3f803f80u + (unsigned)it;
+        ah0 = am0 = al0 = bh0 = bm0 = bl0 = ah1 = am1 = al1 = bh1 = bm1 = bl1 = u32x4{c, c, c, c};
+        asm volatile("" : "+v"(ah0), "+v"(am0), "+v"(al0), "+v"(bh0), "+v"(bm0), "+v"(bl0));
+        asm volatile("" : "+v"(ah1), "+v"(am1), "+v"(al1), "+v"(bh1), "+v"(bm1), "+v"(bl1));
+      } else
       asm volatile(
           "ds_read_b128 %0, %12\n\t"
           "ds_read_b128 %3, %14\n\t"
@@ -213,9 +254,9 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 #define DIC_BF3_M1(A_, B_) \
   acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), acc[0][0], 0, 0, 0);
       DIC_BF3_M1(al0, bh0) DIC_BF3_M1(ah0, bl0) DIC_BF3_M1(am0, bm0)
-      if (more) la.issue((kt0 + it + NSTAGE - 1) * BK3, nx);
+      if (more && ABL == 0) la.issue((kt0 + it + NSTAGE - 1) * BK3, nx);
       DIC_BF3_M1(am0, bh0) DIC_BF3_M1(ah0, bm0) DIC_BF3_M1(ah0, bh0)
-      if (more) lbld.issue((kt0 + it + NSTAGE - 1) * BK3, nx + AOPER);
+      if (more && ABL == 0) lbld.issue((kt0 + it + NSTAGE - 1) * BK3, nx + AOPER);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah1), "+v"(am1), "+v"(al1), "+v"(bh1), "+v"(bm1), "+v"(bl1)::"memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -298,6 +339,7 @@ static int g_bf3_force = 0;     // benchmarking: 11 / 21 / 22 force the 64x64 / 
 void gemm_bf3_force_tile(int code);
 
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
+static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 template <int AK, int TM, int TN>
 static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
   if constexpr (TM == 2) {
@@ -309,6 +351,7 @@ static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
 void gemm_bf3_force_tile(int code) {
   if (code == 42) { g_bf3_stages = 2; return; }
   if (code == 43) { g_bf3_stages = 3; return; }
+  if (code >= 50 && code <= 52) { g_bf3_ablate = code - 50; return; }
   g_bf3_force = code;
 }
 
@@ -346,6 +389,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws) {
   gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (tmv - 1) * 2 + (tnv - 1));
   if (tmv == 2 && tnv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 2>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 2>(p, total, st); }
   else if (tmv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 1>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 1>(p, total, st); }
+  else if (!im && g_bf3_ablate == 1) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 1>), dim3(total), dim3(256), 0, st, p);
+  else if (!im && g_bf3_ablate == 2) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 2>), dim3(total), dim3(256), 0, st, p);
   else { if (im) launch_bf3_variant<OPK_IM2COL, 1, 1>(p, total, st); else launch_bf3_variant<OPK_ROWK, 1, 1>(p, total, st); }
   DIC_LAUNCH_CHECK();
   gemm_profile_mark_end(st);
@@ -366,12 +411,22 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.M = d.M(); p.N = d.CO; p.K = d.K();
   for (int i = 0; i < 3; ++i) { p.A.p[i] = x_planes[i]; p.B.p[i] = w_planes[i]; }
   p.A.kind = (d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) ? OPK_ROWK : OPK_IM2COL;
-  p.A.ld = d.C; p.A.g = d.geom();
-  p.B.kind = OPK_ROWK; p.B.ld = d.K();
+  p.A.ld = d.C; p.A.g = d.geom(); p.A.paired = 1;
+  p.B.kind = OPK_ROWK; p.B.ld = d.K(); p.B.paired = 1;
   p.ep = ep_store(y, d.CO, nullptr, ACT_NONE);
   p.ep.stats = bn_partial;
   DIC_TRY(launch_bf3(p, st, tail_ws));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
+  return DIC_OK;
+}
+
+int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
+                        unsigned short* lo, hipStream_t st) {
+  DIC_REQUIRE(K % 32 == 0 && rows > 0, "split_bf16x3_paired: K %% 32");
+  const long long n4 = ((rows + 1) >> 1) * (K / 2);
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256, 8192);
+  hipLaunchKernelGGL(split_bf16x3_paired_kernel, dim3(blocks), dim3(256), 0, st, x, rows, K, hi, mid, lo);
+  DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
 
@@ -395,17 +450,37 @@ int dic_split_bf16x3(const float* x, long long n, uint16_t* hi, uint16_t* mid, u
   return split_bf16x3(x, n, hi, mid, lo, (hipStream_t)stream);
 }
 
-int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
-                    long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
-                    float* C, long long ldc, const float* bias, void* stream) {
+int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi, uint16_t* mid, uint16_t* lo,
+                            void* stream) {
+  DIC_REQUIRE(x && hi && mid && lo && rows > 0 && K > 0, "split_bf16x3_paired: bad arguments");
+  return split_bf16x3_paired(x, rows, K, hi, mid, lo, (hipStream_t)stream);
+}
+
+static int gemm_bf16x3_any(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
+                           long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
+                           float* C, long long ldc, const float* bias, int paired, void* stream) {
   DIC_REQUIRE(a_hi && a_mid && a_lo && b_hi && b_mid && b_lo && C, "gemm_bf16x3: null pointer");
   DIC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16x3: K, lda, ldb %% 8");
   Bf3Params p{};
   p.M = M; p.N = N; p.K = K;
   p.A.p[0] = a_hi; p.A.p[1] = a_mid; p.A.p[2] = a_lo; p.A.ld = lda; p.A.kind = OPK_ROWK;
   p.B.p[0] = b_hi; p.B.p[1] = b_mid; p.B.p[2] = b_lo; p.B.ld = ldb; p.B.kind = OPK_ROWK;
+  p.A.paired = p.B.paired = paired;
+  if (paired) DIC_REQUIRE(K % 32 == 0, "gemm_bf16x3_paired: K %% 32");
   p.ep = ep_store(C, ldc, bias, ACT_NONE);
   return launch_bf3(p, (hipStream_t)stream, nullptr);
+}
+
+int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
+                    long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
+                    float* C, long long ldc, const float* bias, void* stream) {
+  return gemm_bf16x3_any(M, N, K, a_hi, a_mid, a_lo, lda, b_hi, b_mid, b_lo, ldb, C, ldc, bias, 0, stream);
+}
+
+int dic_gemm_bf16x3_paired(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
+                           const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, float* C, long long ldc,
+                           const float* bias, void* stream) {
+  return gemm_bf16x3_any(M, N, K, a_hi, a_mid, a_lo, K, b_hi, b_mid, b_lo, K, C, ldc, bias, 1, stream);
 }
 
 }  // extern "C"

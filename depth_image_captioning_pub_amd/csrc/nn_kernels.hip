@@ -175,25 +175,36 @@ int bn_apply(const float* x, const float* residual, float* y, long long rows, in
 }
 
 // y = act(x*scale + shift (+ residual)) written as three bf16 planes (operand format of the bf16x3 convolution,
-// gemm_bf3.hip) and optionally also as fp32 (block outputs are the next block's identity).
+// gemm_bf3.hip: row-pair interleaved, plane_offset(..., 1)) and optionally also as fp32 (block outputs are the next
+// block's identity).  16 consecutive threads produce one 128-B plane line: 8 take 32 channels of pixel 2q, 8 the same
+// channels of pixel 2q+1, so the fp32 reads and the plane writes are both whole cache lines.
 __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                                float* __restrict__ y, unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
-                                                               unsigned short* __restrict__ lo, long long n4, int C4,
+                                                               unsigned short* __restrict__ lo, long long rows, int C,
                                                                BnBuf bn, int relu) {
+  const long long n4 = ((rows + 1) >> 1) * (C / 2);
+  const int kb = C / 32;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const int c = (int)(i % C4) * 4;
-    float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 s = *reinterpret_cast<const float4*>(bn.scale + c);
-    const float4 t = *reinterpret_cast<const float4*>(bn.shift + c);
-    v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
-    if (res) {
-      const float4 r = reinterpret_cast<const float4*>(res)[i];
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    const long long line = i >> 4;
+    const int j = (int)(i & 15);
+    const long long r = (line / kb) * 2 + (j >> 3);
+    const int c = (int)(line % kb) * 32 + (j & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const long long src = r * C + c;
+      v = *reinterpret_cast<const float4*>(x + src);
+      const float4 s = *reinterpret_cast<const float4*>(bn.scale + c);
+      const float4 t = *reinterpret_cast<const float4*>(bn.shift + c);
+      v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+      if (res) {
+        const float4 q = *reinterpret_cast<const float4*>(res + src);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (y) *reinterpret_cast<float4*>(y + src) = v;
     }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (y) reinterpret_cast<float4*>(y)[i] = v;
     unsigned short h[4], m[4], l[4];
     split3_bf16(v.x, h[0], m[0], l[0]); split3_bf16(v.y, h[1], m[1], l[1]);
     split3_bf16(v.z, h[2], m[2], l[2]); split3_bf16(v.w, h[3], m[3], l[3]);
@@ -205,10 +216,10 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
 
 int bn_apply_planes(const float* x, const float* residual, float* y, unsigned short* const planes[3], long long rows,
                     int C, BnBuf bn, int relu, hipStream_t st) {
-  DIC_REQUIRE(C % 4 == 0, "bn_apply_planes: C %% 4");
-  const long long n4 = rows * C / 4;
+  DIC_REQUIRE(C % 32 == 0, "bn_apply_planes: C %% 32");
+  const long long n4 = ((rows + 1) >> 1) * (C / 2);
   hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, y, planes[0], planes[1],
-                     planes[2], n4, C / 4, bn, relu);
+                     planes[2], rows, C, bn, relu);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

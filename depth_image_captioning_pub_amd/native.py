@@ -303,8 +303,9 @@ class ResNetRunner:
             tens = [w, w_ohwi]
             if self.mode == 1 and i > 0:             # the C_in = 3 stem stays on the exact-fp32 gather kernel
                 planes = [torch.empty(w_ohwi.numel(), dtype=torch.int16, device=w_ohwi.device) for _ in range(3)]
-                check(lib.dic_split_bf16x3(ptr(w_ohwi), C.c_longlong(w_ohwi.numel()), ptr(planes[0]), ptr(planes[1]),
-                                           ptr(planes[2]), stream_ptr()), "dic_split_bf16x3")
+                check(lib.dic_split_bf16x3_paired(ptr(w_ohwi), C.c_longlong(co), ci * k * k, ptr(planes[0]),
+                                                  ptr(planes[1]), ptr(planes[2]), stream_ptr()),
+                      "dic_split_bf16x3_paired")
                 ent.w_hi, ent.w_mid, ent.w_lo = (pl.data_ptr() for pl in planes)
                 tens += planes
             for field, name in (("gamma", "weight"), ("beta", "bias"), ("running_mean", "running_mean"),

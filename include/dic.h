@@ -170,7 +170,7 @@ typedef struct dic_conv_bn_layer {
   const float* w;                 /* [CO][KH][KW][CI] */
   const float *gamma, *beta;
   float *running_mean, *running_var;
-  const uint16_t *w_hi, *w_mid, *w_lo;   /* mode 1 only: dic_split_bf16x3 of w (same OHWI order); NULL otherwise */
+  const uint16_t *w_hi, *w_mid, *w_lo;   /* mode 1 only: dic_split_bf16x3_paired(w as [CO rows][KH*KW*C]); else NULL */
 } dic_conv_bn_layer;
 
 int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream);
@@ -188,6 +188,14 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
 /* ---- fp32-accurate contraction on the bf16 matrix cores (csrc/gemm_bf3.hip): operands are stored as three bf16
  *      planes hi+mid+lo (exact split of fp32), C = A*B^T from 6 exact bf16 products per k accumulated in fp32. */
 int dic_split_bf16x3(const float* x, long long n, uint16_t* hi, uint16_t* mid, uint16_t* lo, void* stream);
+/* Row-pair interleaved plane layout (the format the convolutions consume; whole-cache-line LDS-DMA fetches): element
+ * (r, k) of a [rows][K] matrix, K % 32 == 0, lives at (((r/2)*(K/32) + k/32)*64 + (r%2)*32 + k%32); each plane holds
+ * ((rows+1) & ~1) * K elements (a zero row pads an odd count). */
+int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi, uint16_t* mid, uint16_t* lo,
+                            void* stream);
+int dic_gemm_bf16x3_paired(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
+                           const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, float* C, long long ldc,
+                           const float* bias, void* stream);
 int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                     long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
                     float* C, long long ldc, const float* bias, void* stream);

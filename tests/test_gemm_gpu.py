@@ -177,3 +177,45 @@ def test_gemm_bf16x3_is_fp32_accurate(lib, M, N, K):
     e3 = float(((C3.cpu().double() - ref).abs() / col).max())
     e1 = float(((C1.cpu().double() - ref).abs() / col).max())
     assert e3 <= 1.5 * e1 + 2e-7, (e3, e1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (197, 131, 96), (1001, 65, 288), (3136, 256, 576)])
+def test_gemm_bf16x3_paired_layout_is_bit_identical(lib, M, N, K):
+    """The row-pair interleaved plane layout (include/dic.h, dic_split_bf16x3_paired: the format the convolutions
+    consume) is a pure relayout: planes hold the same bf16 values at the documented offsets (a zero row pads an odd row
+    count) and the contraction result is bit-identical to the plain-layout kernel, ragged M / N included."""
+    g = torch.Generator().manual_seed(7 * M + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = torch.randn(N, K, generator=g).to(DEV)
+
+    def split_plain(x):
+        out = [torch.empty(x.numel(), dtype=torch.int16, device=DEV) for _ in range(3)]
+        check(lib.dic_split_bf16x3(ptr(x), C.c_longlong(x.numel()), ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+        return out
+
+    def split_paired(x):
+        R = x.shape[0]
+        Rp = (R + 1) // 2 * 2
+        out = [torch.full((Rp * K,), 0x7fff, dtype=torch.int16, device=DEV) for _ in range(3)]
+        check(lib.dic_split_bf16x3_paired(ptr(x), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()),
+              "split_paired")
+        return out
+
+    ap, bp = split_plain(A), split_plain(B)
+    aq, bq = split_paired(A), split_paired(B)
+    for plain, paired, R in ((ap, aq, M), (bp, bq, N)):
+        Rp = (R + 1) // 2 * 2
+        for pl, pq in zip(plain, paired):
+            want = torch.zeros(Rp, K, dtype=torch.int16, device=DEV)
+            want[:R] = pl.view(R, K)
+            want = want.view(Rp // 2, 2, K // 32, 32).permute(0, 2, 1, 3).reshape(-1)
+            assert torch.equal(pq, want)
+    C0 = torch.full((M, N), float("nan"), device=DEV)
+    C1 = torch.full((M, N), float("nan"), device=DEV)
+    check(lib.dic_gemm_bf16x3(M, N, K, ptr(ap[0]), ptr(ap[1]), ptr(ap[2]), C.c_longlong(K), ptr(bp[0]), ptr(bp[1]), ptr(bp[2]),
+                              C.c_longlong(K), ptr(C0), C.c_longlong(N), None, stream_ptr()), "dic_gemm_bf16x3")
+    check(lib.dic_gemm_bf16x3_paired(M, N, K, ptr(aq[0]), ptr(aq[1]), ptr(aq[2]), ptr(bq[0]), ptr(bq[1]), ptr(bq[2]),
+                                     ptr(C1), C.c_longlong(N), None, stream_ptr()), "dic_gemm_bf16x3_paired")
+    assert torch.isfinite(C1).all()
+    assert torch.equal(C0, C1)
