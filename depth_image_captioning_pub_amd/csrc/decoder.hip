@@ -170,54 +170,70 @@ __global__ void __launch_bounds__(128) embed_gather_kernel(const float* __restri
 // row; the HBM-heavy part - one pass over F[b,:,chunk] - is split between them.
 // mode 0: softmax(e); 1: softmax((e+g)/temp); 2: one-hot(argmax(e+g)), g = -log(-log(u)).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) attn_fwd_kernel(
+__global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float* __restrict__ F, const float* __restrict__ P, const float* __restrict__ Hall,
     const float* __restrict__ WhT, const float* __restrict__ b_h, const float* __restrict__ w_full,
     const float* __restrict__ b_full, const float* __restrict__ WbT, const float* __restrict__ b_beta,
     int t, int T, int mode, const float* __restrict__ gumbel_u, int B, float temp,
     float* __restrict__ alphas, float* __restrict__ Qall, float* __restrict__ ctx_all,
     float* __restrict__ gate_all, float* __restrict__ Xall, int do_gate) {
+  // Every phase issues all of its independent loads before the first use (a step is a chain of short phases, each
+  // one memory round trip deep): q 32 loads/thread, scores 13 x 16 B, context + gate 2 x (13 x 16 B + 32 x 4 B).
   __shared__ float h_s[kH];
-  __shared__ float q_s[2][kA];
-  __shared__ float e_s[kL + 4];
-  __shared__ float red_s[8];
-  __shared__ __align__(16) float cred[4][256];
+  __shared__ float q_s[4][kA];
+  __shared__ float e_s[208];
+  __shared__ float red_s[16];
+  __shared__ __align__(16) float cred[8][256];
+  __shared__ float gp_s[2][256];
   const int chunk = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave index as a scalar: every address below is (uniform base) + (small per-lane offset), which keeps the
+  // many loads in flight from costing a 64-bit address register pair each
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long bt = (long long)b * T + t;
 
   if (tid < kH) h_s[tid] = Hall[((long long)b * (T + 1) + t) * kH + tid];
+  if (tid >= 256 && tid < 256 + 12) e_s[kL + tid - 256] = 0.f;      // padding cells of the context loop
   __syncthreads();
-  {  // q = Wh h + bh   (two halves of K per output)
-    const int a = tid & (kA - 1), half = tid >> 7;
+  {  // q = Wh h + bh   (four quarters of K per output)
+    const int a = tid & (kA - 1), quarter = w >> 1;
+    const float* Wq = WhT + quarter * 32 * kA + (w & 1) * 64;
+    float wv[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wv[k] = Wq[k * kA + lane];
     float s = 0.f;
-#pragma unroll 8
-    for (int k = half * 64; k < half * 64 + 64; ++k) s += WhT[k * kA + a] * h_s[k];
-    q_s[half][a] = s;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s += wv[k] * h_s[quarter * 32 + k];
+    q_s[quarter][a] = s;
   }
   __syncthreads();
   if (tid < kA) {
-    const float q = b_h[tid] + q_s[0][tid] + q_s[1][tid];
+    const float q = b_h[tid] + ((q_s[0][tid] + q_s[1][tid]) + (q_s[2][tid] + q_s[3][tid]));
     q_s[0][tid] = q;
     if (chunk == 0 && Qall) Qall[bt * kA + tid] = q;
   }
   if (chunk == 0 && tid < kH && Xall) Xall[bt * kXK + kE + kD + tid] = h_s[tid];   // h_prev slot of the LSTM input
   __syncthreads();
-  {  // e[l] = w . relu(P[l,:] + q) + b : one 32-lane half-wave per cell, float4 per lane
-    const int l32 = lane & 31, sub = lane >> 5;
+  {  // e[l] = w . relu(P[l,:] + q) + b : one 32-lane half-wave per cell, float4 per lane, 16 cells per pass
+    const int l32 = lane & 31, hw = w * 2 + (lane >> 5);
     const float4 q4 = *reinterpret_cast<const float4*>(&q_s[0][l32 * 4]);
     const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
     const float bf = b_full[0];
-    const float* Pb = P + (long long)b * kL * kA;
-    for (int l = w * 2 + sub; l < kL + 7; l += 8) {
-      float s = 0.f;
-      if (l < kL) {
-        const float4 p4 = *reinterpret_cast<const float4*>(Pb + (long long)l * kA + l32 * 4);
-        s = w4.x * fmaxf(p4.x + q4.x, 0.f) + w4.y * fmaxf(p4.y + q4.y, 0.f) + w4.z * fmaxf(p4.z + q4.z, 0.f) +
-            w4.w * fmaxf(p4.w + q4.w, 0.f);
-      }
-      s = half_wave_sum(s);
-      if (l < kL && l32 == 0) e_s[l] = s + bf;
+    const float* Pu = P + (long long)b * kL * kA + w * 2 * kA;          // uniform; + 16*i*kA per pass
+    const unsigned poff = (lane >> 5) * kA + l32 * 4;
+    float4 p4[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      const int l = hw + 16 * i;
+      p4[i] = (l < kL) ? *reinterpret_cast<const float4*>(Pu + 16 * i * kA + poff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      const int l = hw + 16 * i;
+      float sc = w4.x * fmaxf(p4[i].x + q4.x, 0.f) + w4.y * fmaxf(p4[i].y + q4.y, 0.f) +
+                 w4.z * fmaxf(p4[i].z + q4.z, 0.f) + w4.w * fmaxf(p4[i].w + q4.w, 0.f);
+      sc = half_wave_sum(sc);
+      if (l < kL && l32 == 0) e_s[l] = sc + bf;
     }
   }
   __syncthreads();
@@ -234,24 +250,24 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(
     float m = wave_max(z);
     if (lane == 0) red_s[w] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+    m = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));      // cells live in waves 0..3
     float al;
     if (mode == 2) {   // first index attaining the maximum -> one-hot
       int cand = (tid < kL && z == m) ? tid : 0x7fffffff;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
       __syncthreads();
-      if (lane == 0) red_s[4 + w] = __int_as_float(cand);
+      if (lane == 0) red_s[8 + w] = __int_as_float(cand);
       __syncthreads();
-      const int win = min(min(__float_as_int(red_s[4]), __float_as_int(red_s[5])),
-                          min(__float_as_int(red_s[6]), __float_as_int(red_s[7])));
+      const int win = min(min(__float_as_int(red_s[8]), __float_as_int(red_s[9])),
+                          min(__float_as_int(red_s[10]), __float_as_int(red_s[11])));
       al = (tid == win) ? 1.f : 0.f;
     } else {
       const float ex = (tid < kL) ? expf(z - m) : 0.f;
-      const float s = wave_sum(ex);
-      if (lane == 0) red_s[4 + w] = s;
+      const float sm = wave_sum(ex);
+      if (lane == 0) red_s[8 + w] = sm;
       __syncthreads();
-      al = ex / (red_s[4] + red_s[5] + red_s[6] + red_s[7]);
+      al = ex / (red_s[8] + red_s[9] + red_s[10] + red_s[11]);
     }
     __syncthreads();
     if (tid < kL) {
@@ -260,32 +276,52 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(
     }
   }
   __syncthreads();
-  {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk: wave w takes l = w, w+4, ...
-    const float* Fb = F + (long long)b * kL * kD + chunk * 256 + lane * 4;
+  {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk (wave w takes l = w, w+8, ...), fused with the
+     // pre-activation of gate = sigmoid(W_beta h + b) for the same 256 channels (two halves of K per channel)
+    const float* Fu = F + (long long)b * kL * kD + chunk * 256 + (long long)w * kD;      // uniform
+    const unsigned foff = lane * 4;
+    const int dl = tid & 255, half = w >> 2;
+    const float* Wg = WbT + (long long)(half * 64) * kD + chunk * 256 + (w & 3) * 64;           // uniform
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 7
-    for (int l = w; l < kL; l += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(Fb + (long long)l * kD);
-      const float a = e_s[l];
-      acc.x += a * v.x; acc.y += a * v.y; acc.z += a * v.z; acc.w += a * v.w;
+    float gs = 0.f;
+#pragma unroll 1
+    for (int bt2 = 0; bt2 < 2; ++bt2) {
+      float4 v[13];
+      float wv[32];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        const int l = w + 8 * (bt2 * 13 + i);
+        v[i] = (l < kL) ? *reinterpret_cast<const float4*>(Fu + (long long)(8 * (bt2 * 13 + i)) * kD + foff)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (do_gate) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) wv[k] = Wg[(long long)(bt2 * 32 + k) * kD + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        const float a = e_s[w + 8 * (bt2 * 13 + i)];      // padded with zeros up to 208
+        acc.x += a * v[i].x; acc.y += a * v[i].y; acc.z += a * v[i].z; acc.w += a * v[i].w;
+      }
+      if (do_gate) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) gs += wv[k] * h_s[half * 64 + bt2 * 32 + k];
+      }
     }
     *reinterpret_cast<float4*>(&cred[w][lane * 4]) = acc;
+    gp_s[half][dl] = gs;
   }
   __syncthreads();
-  {  // gate = sigmoid(W_beta h + b) ; x = gate * ctx          (depth_models.py:189-190)
+  if (tid < 256) {  // x = gate * ctx          (depth_models.py:189-190)
     const int d = chunk * 256 + tid;
-    const float c = cred[0][tid] + cred[1][tid] + cred[2][tid] + cred[3][tid];
-    if (!do_gate) {            // stand-alone Soft/Hard_Attention.forward: context vector only
-      ctx_all[bt * kD + d] = c;
-      return;
-    }
-    float s = b_beta[d];
-#pragma unroll 8
-    for (int k = 0; k < kH; ++k) s += WbT[(long long)k * kD + d] * h_s[k];
-    const float g = sigmoidf_(s);
+    const float c = ((cred[0][tid] + cred[1][tid]) + (cred[2][tid] + cred[3][tid])) +
+                    ((cred[4][tid] + cred[5][tid]) + (cred[6][tid] + cred[7][tid]));
     ctx_all[bt * kD + d] = c;
-    gate_all[bt * kD + d] = g;
-    Xall[bt * kXK + kE + d] = g * c;
+    if (do_gate) {            // (stand-alone Soft/Hard_Attention.forward stops at the context vector)
+      const float g = sigmoidf_(b_beta[d] + (gp_s[0][tid] + gp_s[1][tid]));
+      gate_all[bt * kD + d] = g;
+      Xall[bt * kXK + kE + d] = g * c;
+    }
   }
 }
 
@@ -301,11 +337,19 @@ __global__ void __launch_bounds__(kH) lstm_fwd_kernel(const float* __restrict__ 
                                                        float* __restrict__ Gact, float* __restrict__ Hdrop) {
   const int b = blockIdx.x, j = threadIdx.x;
   float pre[4];
+  {   // all 4 x nslab partials in flight at once (nslab <= kS_LSTM), summed in slab order
+    float v[4][kS_LSTM];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += slab[((long long)z * nb + b) * kG + q * kH + j];
-    pre[q] = s + bcat[q * kH + j];
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int z = 0; z < kS_LSTM; ++z) v[q][z] = (z < nslab) ? slab[((long long)z * nb + b) * kG + q * kH + j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float sacc = v[q][0];
+#pragma unroll
+      for (int z = 1; z < kS_LSTM; ++z) sacc += v[q][z];
+      pre[q] = sacc + bcat[q * kH + j];
+    }
   }
   const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
   const long long hc = ((long long)b * (T + 1) + t) * kH + j;
@@ -346,10 +390,11 @@ __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
   __syncthreads();
   if (carry) {
     float s = 0.f;
-    for (int z = 0; z < nslab_dx; ++z) s += slab_dx[((long long)z * nb_slab + b) * kXK + kE + kD + j];
+#pragma unroll
+    for (int z = 0; z < kS_DX; ++z) s += (z < nslab_dx) ? slab_dx[((long long)z * nb_slab + b) * kXK + kE + kD + j] : 0.f;
 #pragma unroll
     for (int c = 0; c < kNCH; ++c) s += pbeta[((long long)c * B + b) * kH + j];
-#pragma unroll 8
+#pragma unroll 32
     for (int a = 0; a < kA; ++a) s += dq_s[a] * W_h[a * kH + j];
     dh = s;
     dc = carry_dc[b * kH + j];
@@ -380,22 +425,23 @@ __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
 // the second pass over F[b,:,chunk] (d alpha partial), the W_beta^T dgpre partial for dh_{t-1},
 // and (chunk 0) the embedding-row scatter.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) attn_bwd_a_kernel(
+__global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
     const float* __restrict__ F, const float* __restrict__ slab_dx, int nslab, int nb, int B, int t, int T,
     const float* __restrict__ ctx_all, const float* __restrict__ gate_all, const float* __restrict__ W_beta,
     const long long* __restrict__ cap, int cap_stride, int V, float* __restrict__ dctx_all,
     float* __restrict__ dgpre_all, float* __restrict__ dalp, float* __restrict__ pbeta, float* __restrict__ dembed) {
   __shared__ __align__(16) float dctx_s[256];
   __shared__ float dgp_s[256];
-  __shared__ float pb_s[2][kH];
-  __shared__ float da_s[kL];
+  __shared__ float pb_s[4][kH];
+  __shared__ float da_s[256];
   const int chunk = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
   const long long bt = (long long)b * T + t;
-  {
+  if (tid < 256) {
     const int d = chunk * 256 + tid;
     float dx = 0.f;
-    for (int z = 0; z < nslab; ++z) dx += slab_dx[((long long)z * nb + b) * kXK + kE + d];
+#pragma unroll
+    for (int z = 0; z < kS_DX; ++z) dx += (z < nslab) ? slab_dx[((long long)z * nb + b) * kXK + kE + d] : 0.f;
     const float c = ctx_all[bt * kD + d], g = gate_all[bt * kD + d];
     const float dgp = dx * c * g * (1.f - g);
     const float dcx = dx * g;
@@ -403,36 +449,62 @@ __global__ void __launch_bounds__(256) attn_bwd_a_kernel(
     dctx_all[bt * kD + d] = dcx;
     dctx_s[tid] = dcx;
     dgp_s[tid] = dgp;
-  }
-  if (chunk == 0 && tid < kE) {   // d embed[token] += dX[:, 0:E]   (row scatter; <start> rows collide -> atomics)
+  } else if (chunk == 0 && tid < 256 + kE) {   // d embed[token] += dX[:, 0:E]   (row scatter; <start> rows collide -> atomics)
+    const int e = tid - 256;
     float dx = 0.f;
-    for (int z = 0; z < nslab; ++z) dx += slab_dx[((long long)z * nb + b) * kXK + tid];
+#pragma unroll
+    for (int z = 0; z < kS_DX; ++z) dx += (z < nslab) ? slab_dx[((long long)z * nb + b) * kXK + e] : 0.f;
     long long id = cap[(long long)b * cap_stride + t];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    atomicAdd(dembed + id * kE + tid, dx);
+    atomicAdd(dembed + id * kE + e, dx);
   }
   __syncthreads();
-  {  // partial of W_beta^T dgpre over this chunk's 256 channels
-    const int k = tid & (kH - 1), half = tid >> 7;
-    float s = 0.f;
-    const float* Wb = W_beta + ((long long)chunk * 256 + half * 128) * kH + k;
-#pragma unroll 8
-    for (int d = 0; d < 128; ++d) s += dgp_s[half * 128 + d] * Wb[(long long)d * kH];
-    pb_s[half][k] = s;
-  }
-  {  // d alpha partial: dot(dctx[chunk], F[b,l,chunk]) for l = w, w+4, ...
-    const float4 dc4 = *reinterpret_cast<const float4*>(&dctx_s[lane * 4]);
-    const float* Fb = F + (long long)b * kL * kD + chunk * 256 + lane * 4;
-#pragma unroll 7
-    for (int l = w; l < kL; l += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(Fb + (long long)l * kD);
-      float s = dc4.x * v.x + dc4.y * v.y + dc4.z * v.z + dc4.w * v.w;
-      s = wave_sum(s);
-      if (lane == 0) da_s[l] = s;
+  // Both remaining parts read long-latency data, so all their loads are issued before the first use:
+  //  (1) partial of W_beta^T dgpre over this chunk's 256 channels: output k, four quarters of 64 channels;
+  //  (2) d alpha partial: dot(dctx[chunk], F[b,l,chunk]); a 16-lane group per cell (lane covers channels
+  //      ln*4 + 64*j, so each load instruction reads 256 contiguous bytes per cell), cells l = group + 32*i.
+  const int wv_id = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar wave index -> uniform bases below
+  const int lane = tid & 63;
+  const int k = tid & (kH - 1), quarter = wv_id >> 1;
+  const float* Wb = W_beta + ((long long)chunk * 256 + quarter * 64) * kH + (wv_id & 1) * 64;      // uniform
+  const int ln = tid & 15, grp = tid >> 4;
+  const float* Fu = F + (long long)b * kL * kD + chunk * 256 + (long long)(wv_id * 4) * kD;       // uniform
+  const unsigned foff = (lane >> 4) * kD + ln * 4;
+  float4 dc4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dc4[j] = *reinterpret_cast<const float4*>(&dctx_s[ln * 4 + 64 * j]);
+  float ps = 0.f;
+#pragma unroll 1
+  for (int part = 0; part < 4; ++part) {          // 4 passes x (16 W_beta values + 2 cells x 64 B) per thread
+    float wv[16];
+    float4 v[2][4];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) wv[d] = Wb[(part * 16 + d) * kH + lane];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int l = grp + 32 * (part * 2 + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[i][j] = (l < kL) ? *reinterpret_cast<const float4*>(Fu + (long long)(32 * (part * 2 + i)) * kD + 64 * j + foff)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) ps += dgp_s[quarter * 64 + part * 16 + d] * wv[d];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        sacc += dc4[j].x * v[i][j].x + dc4[j].y * v[i][j].y + dc4[j].z * v[i][j].z + dc4[j].w * v[i][j].w;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+      if (ln == 0) da_s[grp + 32 * (part * 2 + i)] = sacc;       // da_s is padded to 256 cells
     }
   }
+  pb_s[quarter][k] = ps;
   __syncthreads();
-  if (tid < kH) pbeta[((long long)chunk * B + b) * kH + tid] = pb_s[0][tid] + pb_s[1][tid];
+  if (tid < kH)
+    pbeta[((long long)chunk * B + b) * kH + tid] = (pb_s[0][tid] + pb_s[1][tid]) + (pb_s[2][tid] + pb_s[3][tid]);
   if (tid < kL) dalp[((long long)chunk * B + b) * kL + tid] = da_s[tid];
 }
 
@@ -474,26 +546,37 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
   float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), dw4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbf = 0.f;
   const int l_lo = lch * (kL / kLCH), l_hi = l_lo + kL / kLCH;
-  for (int l = l_lo + hw; l < l_hi; l += 8) {
+  constexpr int NIT = (kL / kLCH + 7) / 8;          // 49 cells over 8 half-waves -> 7 passes, all loads up front
+  float4 p4v[NIT], oldv[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int l = l_lo + hw + 8 * i;
     const long long o = ((long long)b * kL + l) * kA + l32 * 4;
-    const float4 p4 = *reinterpret_cast<const float4*>(P + o);
-    const float de = de_s[l];
-    const float r0 = p4.x + q4.x, r1 = p4.y + q4.y, r2 = p4.z + q4.z, r3 = p4.w + q4.w;
-    float4 dp;
-    dp.x = r0 > 0.f ? de * w4.x : 0.f;
-    dp.y = r1 > 0.f ? de * w4.y : 0.f;
-    dp.z = r2 > 0.f ? de * w4.z : 0.f;
-    dp.w = r3 > 0.f ? de * w4.w : 0.f;
-    dq4.x += dp.x; dq4.y += dp.y; dq4.z += dp.z; dq4.w += dp.w;
-    dw4.x += de * fmaxf(r0, 0.f); dw4.y += de * fmaxf(r1, 0.f);
-    dw4.z += de * fmaxf(r2, 0.f); dw4.w += de * fmaxf(r3, 0.f);
-    if (l32 == 0) dbf += de;
-    float4 acc = dp;
-    if (!first_step) {
-      const float4 old = *reinterpret_cast<const float4*>(dPacc + o);
-      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    const bool ok = l < l_hi;
+    p4v[i] = ok ? *reinterpret_cast<const float4*>(P + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    oldv[i] = (ok && !first_step) ? *reinterpret_cast<const float4*>(dPacc + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int l = l_lo + hw + 8 * i;
+    if (l < l_hi) {
+      const long long o = ((long long)b * kL + l) * kA + l32 * 4;
+      const float4 p4 = p4v[i];
+      const float de = de_s[l];
+      const float r0 = p4.x + q4.x, r1 = p4.y + q4.y, r2 = p4.z + q4.z, r3 = p4.w + q4.w;
+      float4 dp;
+      dp.x = r0 > 0.f ? de * w4.x : 0.f;
+      dp.y = r1 > 0.f ? de * w4.y : 0.f;
+      dp.z = r2 > 0.f ? de * w4.z : 0.f;
+      dp.w = r3 > 0.f ? de * w4.w : 0.f;
+      dq4.x += dp.x; dq4.y += dp.y; dq4.z += dp.z; dq4.w += dp.w;
+      dw4.x += de * fmaxf(r0, 0.f); dw4.y += de * fmaxf(r1, 0.f);
+      dw4.z += de * fmaxf(r2, 0.f); dw4.w += de * fmaxf(r3, 0.f);
+      if (l32 == 0) dbf += de;
+      float4 acc = dp;
+      acc.x += oldv[i].x; acc.y += oldv[i].y; acc.z += oldv[i].z; acc.w += oldv[i].w;
+      *reinterpret_cast<float4*>(dPacc + o) = acc;
     }
-    *reinterpret_cast<float4*>(dPacc + o) = acc;
   }
   *reinterpret_cast<float4*>(&acc_s[hw][0][l32 * 4]) = dq4;
   *reinterpret_cast<float4*>(&acc_s[hw][1][l32 * 4]) = dw4;
@@ -700,7 +783,7 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
 
   for (int t = 0; t < T; ++t) {
     const int nb = pl.bs[t];
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, nb), dim3(256), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
                        w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, temp, alphas,
                        ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
     DIC_LAUNCH_CHECK();
@@ -759,7 +842,7 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
     // dX = dG_t * Wcat  (K = 4H)
     DIC_TRY(gemm_slabs(nb, kXK, kG, op_rowk(ws.dG + (long long)t * kG, (long long)T * kG), op_colk(ws.Wcat, kXK),
                        ws.slab_dx, kS_DX, st));
-    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(kNCH, nb), dim3(256), 0, st, ws.F, ws.slab_dx, kS_DX, nb, B, t, T,
+    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.slab_dx, kS_DX, nb, B, t, T,
                        ws.ctx, ws.gate, w->fbeta_w, (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre,
                        ws.dalp, ws.pbeta, g->embed);
     DIC_LAUNCH_CHECK();
@@ -850,7 +933,7 @@ int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rg
   DIC_LAUNCH_CHECK();
   for (int t = 0; t < T; ++t) {
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(kE), 0, st, w->embed, ws.ids, t, T, V, ws.Xall);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(256), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
                        w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, 1.0f, alphas,
                        ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
     DIC_LAUNCH_CHECK();
@@ -893,7 +976,7 @@ int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const floa
                                  hipMemcpyDeviceToDevice, st));
   DIC_TRY(launch_transpose(dec_att_w, WhT, kA, kH, st));
   DIC_TRY(gemm(B * kL, kA, kD, op_rowk(feats, kD), op_rowk(enc_att_w, kD), ep_store(P, kA, enc_att_b), st));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(256), 0, st, feats, (const float*)P, (const float*)H2,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(512), 0, st, feats, (const float*)P, (const float*)H2,
                      (const float*)WhT, dec_att_b, full_att_w, full_att_b, (const float*)nullptr,
                      (const float*)nullptr, 0, 1, mode, gumbel_u, B, temp, alpha, (float*)nullptr, ctx,
                      (float*)nullptr, (float*)nullptr, 0);

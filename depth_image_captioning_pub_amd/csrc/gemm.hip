@@ -434,61 +434,56 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
   gemm_epilogue<BM, BN>(p, acc, tm, tn, z, smem);
 }
 
-// Finishes the remainder tiles of a tail-split launch: sums the K-slice partials, applies the epilogue and writes
-// the BatchNorm column partials of that tile.  grid = remainder tiles; 256 threads = 16 column quads x 16 row
-// groups of 4 rows; every thread first gathers all its slice values with independent 16-B loads.
-__global__ void __launch_bounds__(256) tail_fixup_kernel(const GemmParams p) {
+// Finishes the remainder tiles of a tail-split launch: sums the K-slice partials (fixed order), applies the epilogue
+// and writes the BatchNorm column partials of that tile.  grid = remainder tiles; 1024 threads = 64 rows x 16 column
+// quads.  The slices were written by other XCDs a moment ago, so every load is a long-latency miss: a thread issues
+// all of its (<= 16) slice loads before the first add, which makes the kernel one memory round trip deep.
+constexpr int kTailMaxSplit = 16;
+__global__ void __launch_bounds__(1024) tail_fixup_kernel(const GemmParams p) {
   constexpr int BM = 64, BN = 64;
-  __shared__ float4 sred[2][16][16];
+  __shared__ float4 sred[2][64][16];
+  __shared__ float4 sred2[2][8][16];
   const int t = p.tail_first_tile + blockIdx.x;
   const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
-  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const float* base = p.tail_ws + (long long)blockIdx.x * p.tail_split * BM * BN + (rg * 4) * BN + c4 * 4;
-  float4 v[4];
+  const int c4 = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const float* base = p.tail_ws + (long long)blockIdx.x * p.tail_split * BM * BN + row * BN + c4 * 4;
+  float4 x[kTailMaxSplit];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // slices in groups of four: 16 independent 16-B loads in flight per thread (fixed summation order)
-  for (int s0 = 0; s0 < p.tail_split; s0 += 4) {
-    float4 x[4][4];
+  for (int u = 0; u < kTailMaxSplit; ++u)
+    x[u] = (u < p.tail_split) ? *reinterpret_cast<const float4*>(base + (long long)u * BM * BN)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v = x[0];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        x[u][r] = (s0 + u < p.tail_split)
-                      ? *reinterpret_cast<const float4*>(base + (long long)(s0 + u) * BM * BN + r * BN)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v[r].x += x[u][r].x; v[r].y += x[u][r].y; v[r].z += x[u][r].z; v[r].w += x[u][r].w; }
-  }
-  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cs2 = cs;
+  for (int u = 1; u < kTailMaxSplit; ++u) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
   const int n = tn * BN + c4 * 4;
+  const int m = tm * BM + row;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (m < p.M) {
+    const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = tm * BM + rg * 4 + r;
-    if (m < p.M) {
-      float e[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < p.N) o[j] = finalize_store(p.ep, m, n + j, e[j]);
-      cs.x += o[0]; cs.y += o[1]; cs.z += o[2]; cs.w += o[3];
-      cs2.x += o[0] * o[0]; cs2.y += o[1] * o[1]; cs2.z += o[2] * o[2]; cs2.w += o[3] * o[3];
-    }
+    for (int j = 0; j < 4; ++j)
+      if (n + j < p.N) o[j] = finalize_store(p.ep, m, n + j, e[j]);
   }
-  if (p.ep.stats) {
-    sred[0][rg][c4] = cs;
-    sred[1][rg][c4] = cs2;
+  if (p.ep.stats) {     // column sums / sums of squares over the tile's 64 rows: 8 groups of 8 rows, then the 8 groups
+    sred[0][row][c4] = make_float4(o[0], o[1], o[2], o[3]);
+    sred[1][row][c4] = make_float4(o[0] * o[0], o[1] * o[1], o[2] * o[2], o[3] * o[3]);
     __syncthreads();
-    if (rg < 2) {     // rg 0: sums, rg 1: sums of squares; fixed order over the 16 row groups
-      float4 a = sred[rg][0][c4];
+    if (row < 16) {
+      const int k = row >> 3, part = row & 7;
+      float4 a = sred[k][part * 8][c4];
 #pragma unroll
-      for (int i = 1; i < 16; ++i) { const float4 b = sred[rg][i][c4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-      float o[4] = {a.x, a.y, a.z, a.w};
+      for (int i = 1; i < 8; ++i) { const float4 b = sred[k][part * 8 + i][c4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      sred2[k][part][c4] = a;
+    }
+    __syncthreads();
+    if (row < 2) {
+      float4 a = sred2[row][0][c4];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) { const float4 b = sred2[row][i][c4]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      const float r[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (n + j < p.N) p.ep.stats[((long long)tm * 2 + rg) * p.N + n + j] = o[j];
+        if (n + j < p.N) p.ep.stats[((long long)tm * 2 + row) * p.N + n + j] = r[j];
     }
   }
 }
@@ -745,7 +740,7 @@ static int launch_tile(const GemmParams& p, hipStream_t st) {
 }
 
 int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st) {
-  hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(1024), 0, st, p);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -781,7 +776,7 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   if (dma_ok && tile == 64 && p.splitk == 1 && p.tail_ws != nullptr && g_tail_split_on) {
     const int T = p.mtiles * p.ntiles, r = T % 256;
     int s = r > 0 ? 256 / r : 0;
-    s = std::min(s, std::min(nk / 2, 16));
+    s = std::min(s, std::min(nk / 2, kTailMaxSplit));
     // worth a fix-up launch (~8 us) only on shallow grids, where one partial round is a big share of the time
     if (r > 0 && r <= 128 && s >= 2 && T < 7 * 256) {
       tail_tiles = r;
@@ -818,7 +813,7 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   if (rc != 0) return rc;
   DIC_LAUNCH_CHECK();
   if (tail_tiles > 0 && !g_tail_skip_fix) {
-    hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(1024), 0, st, p);
     DIC_LAUNCH_CHECK();
   }
   if (g_prof_on) {

@@ -22,16 +22,35 @@ __global__ void __launch_bounds__(1024) bn_finalize_train_kernel(const float* __
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int t = g; t < mtiles; t += 32) {
-      a += (double)partial[((long long)t * 2 + 0) * C + c];
-      b += (double)partial[((long long)t * 2 + 1) * C + c];
+  if (c < C) {
+    // the partials were written by other XCDs a moment ago, so every load is a long-latency miss: issue a thread's
+    // loads 8 tiles (16 values) at a time instead of chaining them through the fp64 adds
+    for (int t = g; t < mtiles; t += 32 * 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tt = t + u * 32;
+        const bool ok = tt < mtiles;
+        va[u] = ok ? partial[((long long)tt * 2 + 0) * C + c] : 0.f;
+        vb[u] = ok ? partial[((long long)tt * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
     }
+  }
   s1[g][cl] = a; s2[g][cl] = b;
   __syncthreads();
-  if (g == 0 && c < C) {
+  if (g < 4) {     // 32 partials per channel: four groups add 8 each, then group 0 adds the four
+    a = 0.0; b = 0.0;
 #pragma unroll
-    for (int i = 1; i < 32; ++i) { a += s1[i][cl]; b += s2[i][cl]; }
+    for (int i = 0; i < 8; ++i) { a += s1[g * 8 + i][cl]; b += s2[g * 8 + i][cl]; }
+  }
+  __syncthreads();
+  if (g < 4) { s1[g][cl] = a; s2[g][cl] = b; }
+  __syncthreads();
+  if (g == 0 && c < C) {
+    a = (s1[0][cl] + s1[1][cl]) + (s1[2][cl] + s1[3][cl]);
+    b = (s2[0][cl] + s2[1][cl]) + (s2[2][cl] + s2[3][cl]);
     const double mean = a / count;
     double var = b / count - mean * mean;
     if (var < 0.0) var = 0.0;
