@@ -11,13 +11,13 @@ constexpr int kG = 4 * kH;              // LSTM gate rows (i,f,g,o)
 constexpr int kXK = kE + kD + kH;       // K of the fused LSTM GEMM: [embedding | gate*ctx | h_prev]
 constexpr int kNCH = kD / 256;          // D chunks of 256 channels per workgroup (attention kernels)
 constexpr int kLCH = 4;                 // L chunks of 49 cells (score-backward kernel)
-constexpr int kS_LSTM = 9;              // split-K of the per-step LSTM gate GEMM (72 K tiles)
+constexpr int kS_LSTM = 18;             // split-K of the per-step LSTM gate GEMM (72 K tiles -> 4 per workgroup)
 constexpr int kS_DX = 4;                // split-K of the per-step dX GEMM (16 K tiles)
 
 // workspace ("tape") shared by forward and backward of one decoder call
 struct DecoderWs {
   // forward / saved for backward
-  float *F, *P, *mean, *Wcat, *bcat, *WhT, *WbT, *Xall, *Hall, *Call, *Gact, *Qall, *ctx, *gate, *Hdrop;
+  float *F, *P, *mean, *Wcat, *WcatT, *bcat, *WhT, *WbT, *WzT, *Xall, *Hall, *Call, *Gact, *Qall, *ctx, *gate, *Hdrop;
   float *slab_g, *gemm_ws;
   // backward
   float *dHd, *dG, *slab_dx, *dctx, *dgpre, *dq, *dalp, *pbeta, *dqp, *dwf_acc, *dbf_acc, *dPacc, *carry_dc;

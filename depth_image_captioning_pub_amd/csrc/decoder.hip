@@ -26,9 +26,11 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.P = c.take<float>(BL * kA);
   w.mean = c.take<float>((size_t)B * kD);
   w.Wcat = c.take<float>((size_t)kG * kXK);
+  w.WcatT = c.take<float>((size_t)kG * kXK);
   w.bcat = c.take<float>(kG);
   w.WhT = c.take<float>((size_t)kH * kA);
   w.WbT = c.take<float>((size_t)kH * kD);
+  w.WzT = c.take<float>((size_t)kA * kD);
   w.Xall = c.take<float>(BT * kXK);
   w.Hall = c.take<float>((size_t)B * (T + 1) * kH);
   w.Call = c.take<float>((size_t)B * (T + 1) * kH);
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
+#pragma unroll 8
   for (int m = blockIdx.y; m < M; m += rs) s += X[(long long)m * ld + n];
   out[(long long)blockIdx.y * N + n] = s;
 }
@@ -764,6 +767,7 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
 
   // weight prep: fused LSTM weight, transposed small matrices for coalesced mat-vecs
   hipLaunchKernelGGL(pack_lstm_kernel, dim3(kG), dim3(256), 0, st, w->w_ih, w->w_hh, w->b_ih, w->b_hh, ws.Wcat, ws.bcat);
+  DIC_TRY(launch_transpose(ws.Wcat, ws.WcatT, kG, kXK, st));      // [kXK][4H]: K-contiguous rows for the backward dX GEMM
   DIC_TRY(launch_transpose(w->dec_att_w, ws.WhT, kA, kH, st));
   DIC_TRY(launch_transpose(w->fbeta_w, ws.WbT, kD, kH, st));
   // F = F_rgb + F_depth, mean over cells
@@ -840,7 +844,7 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
                        ws.carry_dc, ws.dG, ws.dq, ws.dinit);
     DIC_LAUNCH_CHECK();
     // dX = dG_t * Wcat  (K = 4H)
-    DIC_TRY(gemm_slabs(nb, kXK, kG, op_rowk(ws.dG + (long long)t * kG, (long long)T * kG), op_colk(ws.Wcat, kXK),
+    DIC_TRY(gemm_slabs(nb, kXK, kG, op_rowk(ws.dG + (long long)t * kG, (long long)T * kG), op_rowk(ws.WcatT, kG),
                        ws.slab_dx, kS_DX, st));
     hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.slab_dx, kS_DX, nb, B, t, T,
                        ws.ctx, ws.gate, w->fbeta_w, (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre,
@@ -894,7 +898,9 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
     DIC_LAUNCH_CHECK();
     GemmEpilogue ep = ep_store(d_features, kD);
     ep.accumulate = 1;
-    DIC_TRY(gemm(B * kL, kD, kA, op_rowk(ws.dPacc, kA), op_colk(w->enc_att_w, kD), ep, st));
+    // dF += dP W_z: W_z^T ([D][A], K-contiguous rows) keeps this 6.6-GFLOP product on the LDS-DMA kernel
+    DIC_TRY(launch_transpose(w->enc_att_w, ws.WzT, kA, kD, st));
+    DIC_TRY(gemm(B * kL, kD, kA, op_rowk(ws.dPacc, kA), op_rowk(ws.WzT, kA), ep, st));
   }
   return DIC_OK;
 }

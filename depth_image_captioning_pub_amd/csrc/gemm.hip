@@ -341,11 +341,15 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
     // RAW: this wave's DMA of tile `it` has landed once at most the younger tiles' instructions are outstanding
     // (vmcnt counts in issue order); the barrier then covers the other waves' pieces.  WAR: the stage refilled
     // below was last read in iteration it-1, which every wave has left when it passes this barrier.
-    if (NSTAGE == 2 || it + NSTAGE - 2 >= nkt) {
+    const int younger = min(NSTAGE - 2, nkt - 1 - it);           // tiles issued after tile `it` and still wanted in flight
+    if (NSTAGE == 2 || younger <= 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
+    } else if (younger == 1) {
       if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     constexpr bool kAsmPath = (TM == 1 && TN == 1);
@@ -800,6 +804,10 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     if (tile == 128) {
       if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_IM2COL, 2>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, OPK_ROWK, 2>), grid, block, 0, st, p);
+    } else if (p.raw_partials && p.A.kind == OPK_ROWK && p.mtiles == 1 && p.ktiles_per_split <= 8) {
+      // skinny split-K slabs (the decoder's per-step GEMMs, M <= 64): a 4-deep ring puts (nearly) the whole K slice
+      // of a workgroup in flight at once - these launches are latency-, not throughput-bound
+      hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_ROWK, 4>), grid, block, 0, st, p);
     } else if (g_dma_stages == 2) {
       if (p.A.kind == OPK_IM2COL) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_IM2COL, 2>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, OPK_ROWK, 2>), grid, block, 0, st, p);

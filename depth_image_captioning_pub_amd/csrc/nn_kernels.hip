@@ -93,9 +93,17 @@ __global__ void __launch_bounds__(256) bn_stats_slice_kernel(const float* __rest
   const int t0 = blockIdx.y * kBnSliceTiles, t1 = min(mtiles, t0 + kBnSliceTiles);
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int t = t0 + g; t < t1; t += 8) {
-      a += (double)partial[((long long)t * 2 + 0) * C + c];
-      b += (double)partial[((long long)t * 2 + 1) * C + c];
+    for (int t = t0 + g; t < t1; t += 64) {               // 8 tiles (16 values) in flight per thread
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tt = t + 8 * u;
+        const bool ok = tt < t1;
+        va[u] = ok ? partial[((long long)tt * 2 + 0) * C + c] : 0.f;
+        vb[u] = ok ? partial[((long long)tt * 2 + 1) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
     }
   s1[g][cl] = a; s2[g][cl] = b;
   __syncthreads();
@@ -447,25 +455,35 @@ int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hi
 }
 
 // BatchNorm backward, stage 1: per (row-chunk, channel) sums of dy and dy*xhat.
-// block = 64 channels (16 float4 lanes) x 16 row lanes; grid (C/64, 64 chunks)
-constexpr int kBnChunks = 64;
+// block = 64 channels (16 float4 lanes) x 16 row lanes; grid (C/64, chunks) with enough row chunks for >= 512 blocks
+constexpr int kBnChunksMax = 256;
+static inline int reduce_chunks(int C) { return std::min(kBnChunksMax, std::max(64, 1024 / std::max(1, C / 64))); }
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              long long rows, int C, BnBuf bn, float* __restrict__ part) {
   __shared__ float4 sa[16][16], sb[16][16];
   const int c4l = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4l * 4;
-  const long long per = (rows + kBnChunks - 1) / kBnChunks;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
   const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   if (c < C) {
     const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
     const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
-    for (long long r = r0 + rl; r < r1; r += 16) {
-      const float4 g = *reinterpret_cast<const float4*>(dy + r * C + c);
-      const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
-      a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-      b.x += g.x * (v.x - mu.x) * is.x; b.y += g.y * (v.y - mu.y) * is.y;
-      b.z += g.z * (v.z - mu.z) * is.z; b.w += g.w * (v.w - mu.w) * is.w;
+    for (long long r = r0 + rl; r < r1; r += 64) {        // 4 rows x 2 tensors in flight per thread
+      float4 g[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long rr = r + 16 * u;
+        const bool ok = rr < r1;
+        g[u] = ok ? *reinterpret_cast<const float4*>(dy + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = ok ? *reinterpret_cast<const float4*>(x + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a.x += g[u].x; a.y += g[u].y; a.z += g[u].z; a.w += g[u].w;
+        b.x += g[u].x * (v[u].x - mu.x) * is.x; b.y += g[u].y * (v[u].y - mu.y) * is.y;
+        b.z += g[u].z * (v[u].z - mu.z) * is.z; b.w += g[u].w * (v[u].w - mu.w) * is.w;
+      }
     }
   }
   sa[rl][c4l] = a; sb[rl][c4l] = b;
@@ -481,13 +499,15 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int C, double rows,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ k2, float* __restrict__ k3) {
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C,
+                                                               double rows, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ k2,
+                                                               float* __restrict__ k3) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
-  for (int t = 0; t < kBnChunks; ++t) {
+#pragma unroll 8
+  for (int t = 0; t < chunks; ++t) {
     a += (double)part[((long long)t * 2 + 0) * C + c];
     b += (double)part[((long long)t * 2 + 1) * C + c];
   }
@@ -520,17 +540,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ d
   }
 }
 
-size_t bn_backward_ws_floats(int C) { return (size_t)kBnChunks * 2 * C + 2 * (size_t)C; }
+size_t bn_backward_ws_floats(int C) { return (size_t)kBnChunksMax * 2 * C + 2 * (size_t)C; }
 
 int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
                 float* dbeta, float* ws, hipStream_t st) {
   DIC_REQUIRE(C % 64 == 0, "bn_backward: C %% 64");
   float* part = ws;
-  float* k2 = ws + (size_t)kBnChunks * 2 * C;
+  float* k2 = ws + (size_t)kBnChunksMax * 2 * C;
   float* k3 = k2 + C;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C / 64, kBnChunks), dim3(256), 0, st, dy_dx, x, rows, C, bn, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, C, (double)rows, dgamma,
-                     dbeta, k2, k3);
+  const int chunks = reduce_chunks(C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C / 64, chunks), dim3(256), 0, st, dy_dx, x, rows, C, bn, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, chunks, C, (double)rows,
+                     dgamma, dbeta, k2, k3);
   const long long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy_dx, x, n4, C / 4, gamma, bn, k2, k3);
   DIC_LAUNCH_CHECK();
@@ -548,9 +569,15 @@ __global__ void __launch_bounds__(256) colsum_rows_v4_kernel(const float* __rest
   const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C)
-    for (long long r = r0 + rl; r < r1; r += 16) {
-      const float4 g = *reinterpret_cast<const float4*>(X + r * ld + c);
-      a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+    for (long long r = r0 + rl; r < r1; r += 128) {       // 8 rows in flight per thread
+      float4 g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long rr = r + 16 * u;
+        g[u] = (rr < r1) ? *reinterpret_cast<const float4*>(X + rr * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += g[u].x; a.y += g[u].y; a.z += g[u].z; a.w += g[u].w; }
     }
   sa[rl][c4l] = a;
   __syncthreads();
@@ -568,6 +595,7 @@ __global__ void __launch_bounds__(256) colsum_rows_kernel(const float* __restric
   const long long per = (rows + chunks - 1) / chunks;
   const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
   float s = 0.f;
+#pragma unroll 8
   for (long long r = r0; r < r1; ++r) s += X[r * ld + c];
   out[(long long)blockIdx.y * C + c] = s;
 }
@@ -575,7 +603,7 @@ __global__ void __launch_bounds__(256) colsum_rows_kernel(const float* __restric
 int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st) {
   const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && rows >= 256;
   if (v4) {
-    const int chunks = 64;
+    const int chunks = reduce_chunks(C);                  // ws holds up to 256 x C partial rows
     hipLaunchKernelGGL(colsum_rows_v4_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, X, ld, rows, C, ws);
     hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, ws, (long long)C,
                        (long long)chunks, C, out, 1);
