@@ -63,7 +63,7 @@ def profile_step(trainer, args_step):
         k = keys[i]
         if k >= 2000:                                   # split-bf16 convolution kernel (gemm_bf3.hip)
             a = (k - 2000) // 10
-            rows.append({"kernel": f"gemm_bf3_kernel<{KIND_NAMES[a]}>", "rocprof_name": f"gemm_bf3_kernel<{a}, 2>",
+            rows.append({"kernel": f"gemm_bf3_kernel<{KIND_NAMES[a]}>", "rocprof_name": f"gemm_bf3_kernel<{a}, 1, 1, 2, 0>",
                          "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "peak": PEAK_BF16X3_TFLOPS})
             continue
         dma = k >= 1000
@@ -81,9 +81,10 @@ def profile_step(trainer, args_step):
 
 def pmc_for(rocprof_name: str):
     """(HBM bytes per launch, MFMA utilisation) of a kernel from the committed PMC summary, or (None, None)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")))    # newest round last
     try:
-        for rec in json.load(open(path)):
+        for rec in json.load(open(paths[-1])):
             if rocprof_name in rec["kernel"]:
                 return round(rec["hbm_bytes_per_launch_corrected"]), round(rec.get("mfma_util", 0.0), 4) or None
     except Exception:
@@ -247,7 +248,7 @@ def main():
                     "frac": round(ach / peak, 4), "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic,
                     "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE x2 gfx950 "
-                                    "wide-read correction + WRITE_SIZE, KB->bytes), profiles/r01_pmc_per_kernel.json",
+                                    "wide-read correction + WRITE_SIZE, KB->bytes), profiles/r01d_pmc_per_kernel.json (scripts/pmc_summary.py)",
                     "mfma_util_pmc": mfma_util,
                     "launches_per_step": top["launches"],
                     "avg_launch_us": round(top["total_ms"] * 1e3 / top["launches"], 2),

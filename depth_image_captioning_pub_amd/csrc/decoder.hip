@@ -222,13 +222,12 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float4 q4 = *reinterpret_cast<const float4*>(&q_s[0][l32 * 4]);
     const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
     const float bf = b_full[0];
-    const float* Pu = P + (long long)b * kL * kA + w * 2 * kA;          // uniform; + 16*i*kA per pass
-    const unsigned poff = (lane >> 5) * kA + l32 * 4;
+    const float* Pu = P + (long long)b * kL * kA;                       // uniform
     float4 p4[13];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-      const int l = hw + 16 * i;
-      p4[i] = (l < kL) ? *reinterpret_cast<const float4*>(Pu + 16 * i * kA + poff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 13; ++i) {      // branch-free guard: cells past the end re-read the last cell (never stored)
+      const unsigned poff = (unsigned)min(hw + 16 * i, kL - 1) * kA + l32 * 4;
+      p4[i] = *reinterpret_cast<const float4*>(Pu + poff);
     }
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
@@ -281,7 +280,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   __syncthreads();
   {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk (wave w takes l = w, w+8, ...), fused with the
      // pre-activation of gate = sigmoid(W_beta h + b) for the same 256 channels (two halves of K per channel)
-    const float* Fu = F + (long long)b * kL * kD + chunk * 256 + (long long)w * kD;      // uniform
+    const float* Fu = F + (long long)b * kL * kD + chunk * 256;                              // uniform
     const unsigned foff = lane * 4;
     const int dl = tid & 255, half = w >> 2;
     const float* Wg = WbT + (long long)(half * 64) * kD + chunk * 256 + (w & 3) * 64;           // uniform
@@ -293,9 +292,8 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
       float wv[32];
 #pragma unroll
       for (int i = 0; i < 13; ++i) {
-        const int l = w + 8 * (bt2 * 13 + i);
-        v[i] = (l < kL) ? *reinterpret_cast<const float4*>(Fu + (long long)(8 * (bt2 * 13 + i)) * kD + foff)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int l = min(w + 8 * (bt2 * 13 + i), kL - 1);      // padding cells re-read the last cell, weight e_s = 0
+        v[i] = *reinterpret_cast<const float4*>(Fu + (long long)l * kD + foff);
       }
       if (do_gate) {
 #pragma unroll
@@ -471,8 +469,7 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
   const int k = tid & (kH - 1), quarter = wv_id >> 1;
   const float* Wb = W_beta + ((long long)chunk * 256 + quarter * 64) * kH + (wv_id & 1) * 64;      // uniform
   const int ln = tid & 15, grp = tid >> 4;
-  const float* Fu = F + (long long)b * kL * kD + chunk * 256 + (long long)(wv_id * 4) * kD;       // uniform
-  const unsigned foff = (lane >> 4) * kD + ln * 4;
+  const float* Fu = F + (long long)b * kL * kD + chunk * 256;                                       // uniform
   float4 dc4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) dc4[j] = *reinterpret_cast<const float4*>(&dctx_s[ln * 4 + 64 * j]);
@@ -488,8 +485,7 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
       const int l = grp + 32 * (part * 2 + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        v[i][j] = (l < kL) ? *reinterpret_cast<const float4*>(Fu + (long long)(32 * (part * 2 + i)) * kD + 64 * j + foff)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i][j] = *reinterpret_cast<const float4*>(Fu + (unsigned)min(l, kL - 1) * kD + ln * 4 + 64 * j);   // branch-free guard
     }
 #pragma unroll
     for (int d = 0; d < 16; ++d) ps += dgp_s[quarter * 64 + part * 16 + d] * wv[d];
@@ -553,11 +549,11 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
   float4 p4v[NIT], oldv[NIT];
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int l = l_lo + hw + 8 * i;
+    const int l = min(l_lo + hw + 8 * i, l_hi - 1);
     const long long o = ((long long)b * kL + l) * kA + l32 * 4;
-    const bool ok = l < l_hi;
-    p4v[i] = ok ? *reinterpret_cast<const float4*>(P + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-    oldv[i] = (ok && !first_step) ? *reinterpret_cast<const float4*>(dPacc + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    p4v[i] = *reinterpret_cast<const float4*>(P + o);                 // clamped cell: branch-free, unused when l >= l_hi
+    oldv[i] = *reinterpret_cast<const float4*>(dPacc + o);
+    if (first_step) oldv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {

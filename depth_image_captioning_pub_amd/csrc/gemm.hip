@@ -443,6 +443,7 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
 // quads.  The slices were written by other XCDs a moment ago, so every load is a long-latency miss: a thread issues
 // all of its (<= 16) slice loads before the first add, which makes the kernel one memory round trip deep.
 constexpr int kTailMaxSplit = 16;
+template <int NS>      // NS = slice loads issued per thread (2/4/8/16 >= tail_split; the surplus re-reads the last slice)
 __global__ void __launch_bounds__(1024) tail_fixup_kernel(const GemmParams p) {
   constexpr int BM = 64, BN = 64;
   __shared__ float4 sred[2][64][16];
@@ -451,14 +452,15 @@ __global__ void __launch_bounds__(1024) tail_fixup_kernel(const GemmParams p) {
   const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
   const int c4 = threadIdx.x & 15, row = threadIdx.x >> 4;
   const float* base = p.tail_ws + (long long)blockIdx.x * p.tail_split * BM * BN + row * BN + c4 * 4;
-  float4 x[kTailMaxSplit];
+  float4 x[NS];
 #pragma unroll
-  for (int u = 0; u < kTailMaxSplit; ++u)
-    x[u] = (u < p.tail_split) ? *reinterpret_cast<const float4*>(base + (long long)u * BM * BN)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < NS; ++u) {     // branch-free guard: clamped slice, zeroed afterwards
+    x[u] = *reinterpret_cast<const float4*>(base + (long long)min(u, p.tail_split - 1) * BM * BN);
+    if (u >= p.tail_split) x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float4 v = x[0];
 #pragma unroll
-  for (int u = 1; u < kTailMaxSplit; ++u) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
+  for (int u = 1; u < NS; ++u) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
   const int n = tn * BN + c4 * 4;
   const int m = tm * BM + row;
   float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -744,7 +746,11 @@ static int launch_tile(const GemmParams& p, hipStream_t st) {
 }
 
 int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st) {
-  hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(1024), 0, st, p);
+  const dim3 g(tail_tiles), b(1024);
+  if (p.tail_split <= 2) hipLaunchKernelGGL(tail_fixup_kernel<2>, g, b, 0, st, p);
+  else if (p.tail_split <= 4) hipLaunchKernelGGL(tail_fixup_kernel<4>, g, b, 0, st, p);
+  else if (p.tail_split <= 8) hipLaunchKernelGGL(tail_fixup_kernel<8>, g, b, 0, st, p);
+  else hipLaunchKernelGGL(tail_fixup_kernel<16>, g, b, 0, st, p);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -821,7 +827,11 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   if (rc != 0) return rc;
   DIC_LAUNCH_CHECK();
   if (tail_tiles > 0 && !g_tail_skip_fix) {
-    hipLaunchKernelGGL(tail_fixup_kernel, dim3(tail_tiles), dim3(1024), 0, st, p);
+    const dim3 g(tail_tiles), b(1024);
+  if (p.tail_split <= 2) hipLaunchKernelGGL(tail_fixup_kernel<2>, g, b, 0, st, p);
+  else if (p.tail_split <= 4) hipLaunchKernelGGL(tail_fixup_kernel<4>, g, b, 0, st, p);
+  else if (p.tail_split <= 8) hipLaunchKernelGGL(tail_fixup_kernel<8>, g, b, 0, st, p);
+  else hipLaunchKernelGGL(tail_fixup_kernel<16>, g, b, 0, st, p);
     DIC_LAUNCH_CHECK();
   }
   if (g_prof_on) {

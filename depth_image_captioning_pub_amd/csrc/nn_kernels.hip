@@ -28,11 +28,12 @@ __global__ void __launch_bounds__(1024) bn_finalize_train_kernel(const float* __
     for (int t = g; t < mtiles; t += 32 * 8) {
       float va[8], vb[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int tt = t + u * 32;
-        const bool ok = tt < mtiles;
-        va[u] = ok ? partial[((long long)tt * 2 + 0) * C + c] : 0.f;
-        vb[u] = ok ? partial[((long long)tt * 2 + 1) * C + c] : 0.f;
+      for (int u = 0; u < 8; ++u) {     // branch-free guard: clamped address, select afterwards (a predicated load
+        const int tt = t + u * 32;      // would be followed by vmcnt(0) and serialise the batch)
+        const int tc = min(tt, mtiles - 1);
+        const float xa = partial[((long long)tc * 2 + 0) * C + c], xb = partial[((long long)tc * 2 + 1) * C + c];
+        va[u] = tt < mtiles ? xa : 0.f;
+        vb[u] = tt < mtiles ? xb : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
@@ -98,9 +99,10 @@ __global__ void __launch_bounds__(256) bn_stats_slice_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int tt = t + 8 * u;
-        const bool ok = tt < t1;
-        va[u] = ok ? partial[((long long)tt * 2 + 0) * C + c] : 0.f;
-        vb[u] = ok ? partial[((long long)tt * 2 + 1) * C + c] : 0.f;
+        const int tc = min(tt, t1 - 1);                    // branch-free guard (see bn_finalize_train_kernel)
+        const float xa = partial[((long long)tc * 2 + 0) * C + c], xb = partial[((long long)tc * 2 + 1) * C + c];
+        va[u] = tt < t1 ? xa : 0.f;
+        vb[u] = tt < t1 ? xb : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
@@ -474,9 +476,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long rr = r + 16 * u;
-        const bool ok = rr < r1;
-        g[u] = ok ? *reinterpret_cast<const float4*>(dy + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[u] = ok ? *reinterpret_cast<const float4*>(x + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const long long rc = min(rr, r1 - 1);              // branch-free guard: clamped row, zeroed afterwards
+        g[u] = *reinterpret_cast<const float4*>(dy + rc * C + c);
+        v[u] = *reinterpret_cast<const float4*>(x + rc * C + c);
+        if (rr >= r1) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -574,7 +577,8 @@ __global__ void __launch_bounds__(256) colsum_rows_v4_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const long long rr = r + 16 * u;
-        g[u] = (rr < r1) ? *reinterpret_cast<const float4*>(X + rr * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[u] = *reinterpret_cast<const float4*>(X + min(rr, r1 - 1) * ld + c);     // branch-free guard
+        if (rr >= r1) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { a.x += g[u].x; a.y += g[u].y; a.z += g[u].z; a.w += g[u].w; }
