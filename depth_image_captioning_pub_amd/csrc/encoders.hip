@@ -214,10 +214,12 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       const RnConv& c2 = pl.convs[ci++];
       const RnConv& c3 = pl.convs[ci++];
       DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], A, ws, train_bn, st));
-      DIC_TRY(bn_apply_planes(A, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st));
+      DIC_TRY(bn_apply_planes(A, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st));
       DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], Bf, ws, train_bn, st));
-      DIC_TRY(bn_apply_planes(Bf, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn, 1, st));
-      const float* identity = X;
+      DIC_TRY(bn_apply_planes(Bf, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn, 1, st));
+      // identity: the block input, which exists only as planes ((hi + mid) + lo is the fp32 value exactly), or the
+      // fp32 output of the downsample branch in the first block of a stage
+      const float* identity = nullptr;
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
         DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st));
@@ -225,9 +227,12 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
         identity = Cf;
       }
       DIC_TRY(conv_bn_bf3(P2, c3.d, layers[c3.layer], A, ws, train_bn, st));
-      // out = relu(bn3 + identity): fp32 (next identity) into Bf, planes (next conv input) into P1 (free again)
-      DIC_TRY(bn_apply_planes(A, identity, Bf, P1, c3.d.M(), c3.d.CO, ws.bn, 1, st));
-      std::swap(X, Bf);
+      // out = relu(bn3 + identity) as planes (next conv input / next identity) into P1 (free again); only the very last
+      // block also writes fp32, for the pooling that follows
+      const bool last = (s == 3 && b == blocks[s] - 1);
+      const unsigned short* idp[3] = {Xp[0], Xp[1], Xp[2]};
+      DIC_TRY(bn_apply_planes(A, identity, identity ? nullptr : idp, last ? X : nullptr, P1, c3.d.M(), c3.d.CO, ws.bn, 1,
+                              st));
       std::swap(Xp, P1);
     }
   return adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, 14, features, st);

@@ -208,6 +208,9 @@ int bn_apply(const float* x, const float* residual, float* y, long long rows, in
 // block's identity).  16 consecutive threads produce one 128-B plane line: 8 take 32 channels of pixel 2q, 8 the same
 // channels of pixel 2q+1, so the fp32 reads and the plane writes are both whole cache lines.
 __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                               const unsigned short* __restrict__ rhi,
+                                                               const unsigned short* __restrict__ rmid,
+                                                               const unsigned short* __restrict__ rlo,
                                                                float* __restrict__ y, unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
                                                                unsigned short* __restrict__ lo, long long rows, int C,
@@ -230,6 +233,13 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
       if (res) {
         const float4 q = *reinterpret_cast<const float4*>(res + src);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      } else if (rhi) {   // residual given as planes of the same layout: (hi + mid) + lo is the fp32 value, exactly
+        const uint2 a = reinterpret_cast<const uint2*>(rhi)[i], b = reinterpret_cast<const uint2*>(rmid)[i],
+                    d = reinterpret_cast<const uint2*>(rlo)[i];
+        v.x += (__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16)) + __uint_as_float(d.x << 16);
+        v.y += (__uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u)) + __uint_as_float(d.x & 0xffff0000u);
+        v.z += (__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16)) + __uint_as_float(d.y << 16);
+        v.w += (__uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u)) + __uint_as_float(d.y & 0xffff0000u);
       }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (y) *reinterpret_cast<float4*>(y + src) = v;
@@ -243,12 +253,16 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
   }
 }
 
-int bn_apply_planes(const float* x, const float* residual, float* y, unsigned short* const planes[3], long long rows,
-                    int C, BnBuf bn, int relu, hipStream_t st) {
+int bn_apply_planes(const float* x, const float* residual, const unsigned short* const residual_planes[3], float* y,
+                    unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st) {
+  DIC_REQUIRE(!(residual && residual_planes), "bn_apply_planes: give the residual as fp32 or as planes, not both");
   DIC_REQUIRE(C % 32 == 0, "bn_apply_planes: C %% 32");
   const long long n4 = ((rows + 1) >> 1) * (C / 2);
-  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, y, planes[0], planes[1],
-                     planes[2], rows, C, bn, relu);
+  const unsigned short* r0 = residual_planes ? residual_planes[0] : nullptr;
+  const unsigned short* r1 = residual_planes ? residual_planes[1] : nullptr;
+  const unsigned short* r2 = residual_planes ? residual_planes[2] : nullptr;
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, r0, r1, r2, y, planes[0],
+                     planes[1], planes[2], rows, C, bn, relu);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
