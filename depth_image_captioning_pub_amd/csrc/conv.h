@@ -25,7 +25,12 @@ int conv_mtiles(const ConvDesc& d, int force_tile = 0);
 // ([CO rows][KH*KW*C]) are given as three bf16 planes (hi, mid, lo) each, in the row-pair interleaved layout
 // (plane_offset(..., paired = 1), gemm.h); output is raw fp32 + the same BN partial sums as conv_fwd (64-row M tiles).
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
-                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st);
+                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st,
+                 const float* bias = nullptr);
+// data gradient of a stride-1 convolution through the same kernel: dy planes [B,OH,OW,CO], flipped weights
+// [C][KH][KW][CO] planes (conv_flip_weights + split), dx fp32 [B,H,W,C]
+int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
+                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st);
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
                         unsigned short* lo, hipStream_t st);

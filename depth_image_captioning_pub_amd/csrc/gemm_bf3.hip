@@ -405,7 +405,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws) {
 
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
-                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st) {
+                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
   Bf3Params p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -413,11 +413,19 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.A.kind = (d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) ? OPK_ROWK : OPK_IM2COL;
   p.A.ld = d.C; p.A.g = d.geom(); p.A.paired = 1;
   p.B.kind = OPK_ROWK; p.B.ld = d.K(); p.B.paired = 1;
-  p.ep = ep_store(y, d.CO, nullptr, ACT_NONE);
+  p.ep = ep_store(y, d.CO, bias, ACT_NONE);
   p.ep.stats = bn_partial;
   DIC_TRY(launch_bf3(p, st, tail_ws));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
   return DIC_OK;
+}
+
+int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
+                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st) {
+  DIC_REQUIRE(d.stride == 1 && d.CO % 32 == 0, "conv_dgrad_s1_bf3: stride 1, CO %% 32");
+  // full correlation of dY (an [OH,OW,CO] image) with the flipped kernel, padding KH-1-pad
+  const ConvDesc dd{d.B, d.OH(), d.OW(), d.CO, d.C, d.KH, d.KW, 1, d.KH - 1 - d.pad, 0};
+  return conv_fwd_bf3(dy_planes, dd, wflip_planes, dx, nullptr, nullptr, nullptr, st, nullptr);
 }
 
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
