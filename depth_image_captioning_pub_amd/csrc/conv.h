@@ -29,6 +29,12 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
                  const float* bias = nullptr);
 // data gradient of a stride-1 convolution through the same kernel: dy planes [B,OH,OW,CO], flipped weights
 // [C][KH][KW][CO] planes (conv_flip_weights + split), dx fp32 [B,H,W,C]
+// weight gradient through the same kernel (split-K over the output pixels); dyT / pT: scratch planes of
+// conv_wgrad_bf3_plane_elems(d, 0 / 1) elements each, ws: conv_wgrad_bf3_ws_floats(d, splitk) floats
+size_t conv_wgrad_bf3_plane_elems(const ConvDesc& d, int which);
+size_t conv_wgrad_bf3_ws_floats(const ConvDesc& d, int splitk);
+int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk,
+                   unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st);
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
                       const unsigned short* const wflip_planes[3], float* dx, hipStream_t st);
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);

@@ -39,6 +39,8 @@ static DepthGeom depth_geom(int B, int H, int W) {
 
 constexpr int kWg1Split = 128;   // split-K of the conv1 weight gradient (K = B*73*73)
 constexpr int kWg2Split = 4;
+constexpr int kWg2SplitBf3 = 5;   // conv2 weight gradient on the bf16x3 kernel: 144 output tiles x 5 K slices
+constexpr int kWg3SplitBf3 = 3;   // conv3: 256 tiles x 3
 
 struct DepthWs {
   float *w2o, *x1, *y1p, *x2, *y2p, *x3, *partial;
@@ -49,6 +51,8 @@ struct DepthWs {
   float *dy1, *dy1p, *dy2, *dy2p, *dy3, *w2f, *w3f, *dw2o, *wg_ws, *bn_ws, *cs_ws;
   // bf16x3 operands of conv2 (forward and data gradient run on gemm_bf3.hip): planes of pooled1, W2, dY2, flipped W2
   unsigned short *y1p_pl[3], *w2_pl[3], *dy2_pl[3], *w2f_pl[3];
+  unsigned short *wg_dyT[3], *wg_pT[3];     // weight-gradient operands (transposed planes), shared by conv2 / conv3
+  float* wg_bf3_ws;
   size_t bytes;
 };
 
@@ -93,7 +97,10 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
     w.w2_pl[i] = c.take<unsigned short>((size_t)512 * 1152);
     w.dy2_pl[i] = c.take<unsigned short>((size_t)(g.M2 + 1) * 512);
     w.w2f_pl[i] = c.take<unsigned short>((size_t)128 * 4608);
+    w.wg_dyT[i] = c.take<unsigned short>(std::max(conv_wgrad_bf3_plane_elems(g.c2, 0), conv_wgrad_bf3_plane_elems(g.c3, 0)));
+    w.wg_pT[i] = c.take<unsigned short>(std::max(conv_wgrad_bf3_plane_elems(g.c2, 1), conv_wgrad_bf3_plane_elems(g.c3, 1)));
   }
+  w.wg_bf3_ws = c.take<float>(std::max(conv_wgrad_bf3_ws_floats(g.c2, kWg2SplitBf3), conv_wgrad_bf3_ws_floats(g.c3, kWg3SplitBf3)));
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
   return w;
@@ -314,14 +321,14 @@ int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth
   DIC_TRY(adaptive_avgpool_bwd(d_features, B, g.P2h, g.P2w, 2048, 14, ws.dy3, st));
   DIC_TRY(relu_mask_bwd(ws.dy3, ws.x3, g.M3, 2048, ws.bn3, st));
   DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st));
-  DIC_TRY(conv_wgrad(ws.y2p, g.c3, ws.dy3, gr->conv3_w, 1, nullptr, st));        // OHWI == OIHW for 1x1
+  DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));   // OHWI == OIHW for 1x1
   DIC_TRY(colsum_rows(ws.dy3, 2048, g.M3, 2048, gr->conv3_b, ws.cs_ws, st));
   DIC_TRY(conv_flip_weights(w->conv3_w, g.c3, ws.w3f, st));
   DIC_TRY(conv_dgrad_s1(ws.dy3, g.c3, ws.w3f, ws.dy2p, st));
   // layer 2
   DIC_TRY(maxpool_relu_bwd(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, ws.bn2, ws.dy2, st));
   DIC_TRY(bn_backward(ws.dy2, ws.x2, g.M2, 512, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b, ws.bn_ws, st));
-  DIC_TRY(conv_wgrad(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2Split, ws.wg_ws, st));
+  DIC_TRY(conv_wgrad_bf3(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));
   DIC_TRY(ohwi_to_oihw(ws.dw2o, gr->conv2_w, 512, 128, 3, 3, st));
   DIC_TRY(colsum_rows(ws.dy2, 512, g.M2, 512, gr->conv2_b, ws.cs_ws, st));
   DIC_TRY(conv_flip_weights(ws.w2o, g.c2, ws.w2f, st));

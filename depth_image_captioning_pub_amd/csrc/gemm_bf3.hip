@@ -355,7 +355,7 @@ void gemm_bf3_force_tile(int code) {
   g_bf3_force = code;
 }
 
-static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws) {
+static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 1, float* splitk_ws = nullptr) {
   // tile choice (measured, scripts/bench_bf3.py): bigger per-wave tiles halve the LDS fragment traffic per MFMA and
   // amortise the per-K-tile barrier, but need >= ~2 workgroups per CU to keep 256 CUs busy
   int tmv = 1, tnv = 1;
@@ -376,6 +376,17 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws) {
   int total = T;
   p.tail_first_block = T; p.tail_first_tile = 0; p.tail_split = 1; p.tail_ws = nullptr;
   int tail_tiles = 0;
+  if (splitk > 1) {   // split-K over every tile (weight gradients: few tiles, very long K): all tiles go through the
+                      // slice + tail_fixup machinery, slices summed in fixed order
+    DIC_REQUIRE(splitk_ws != nullptr && splitk <= 16, "gemm_bf3: split-K needs a workspace and <= 16 slices");
+    tmv = 1; tnv = 1;
+    p.mtiles = ceil_div(p.M, 64); p.ntiles = ceil_div(p.N, 64);
+    g_last_mtiles = p.mtiles;
+    const int T2 = p.mtiles * p.ntiles;
+    splitk = std::min(splitk, std::max(1, nk / 2));
+    tail_tiles = T2; p.tail_first_tile = 0; p.tail_first_block = 0; p.tail_split = splitk; p.tail_ws = splitk_ws;
+    total = T2 * splitk;
+  } else
   if (tail_ws && tmv == 1 && tnv == 1) {
     const int r = T % 256;
     int sp = r > 0 ? 256 / r : 0;
@@ -418,6 +429,91 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   DIC_TRY(launch_bf3(p, st, tail_ws));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
   return DIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on the bf16x3 kernel: dW[co][(kh,kw,c)] = sum_m dY[m][co] * patch(m)[(kh,kw,c)] is a contraction over
+// the output pixels m, so both operands are needed with m contiguous.  Two producers write them as paired planes
+// (K = M rounded up to 32, zero filled): transpose_split (dY^T) and im2col_transpose_split (patch^T); the product then
+// runs as a split-K launch (few output tiles, K in the ten thousands).
+// One workgroup = a 32 (m) x 32 (column) tile through LDS; 16 consecutive threads write one 128-B plane line.
+// ------------------------------------------------------------------------------------------
+template <bool IM2COL>
+__global__ void __launch_bounds__(256) transpose_split_kernel(const float* __restrict__ x, long long ld, int M, int Kpad,
+                                                               int ncols, ConvGeom g, unsigned short* __restrict__ hi,
+                                                               unsigned short* __restrict__ mid,
+                                                               unsigned short* __restrict__ lo) {
+  __shared__ float tile[32][33];
+  const int m0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  int c0, tap = 0;                       // first source column of this tile (and the filter tap for im2col)
+  if constexpr (IM2COL) {
+    const int cb = g.C / 32;
+    tap = blockIdx.y / cb;
+    c0 = (blockIdx.y - tap * cb) * 32;
+  } else {
+    c0 = blockIdx.y * 32;
+  }
+  {  // load: thread (mrow, c4) reads 4 consecutive columns of one source row
+    const int mrow = tid >> 3, c4 = (tid & 7) * 4;
+    const int m = m0 + mrow;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
+      if constexpr (IM2COL) {
+        const int ohw = g.OH * g.OW;
+        const int img = m / ohw, rem = m - img * ohw;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        const int ih = oh * g.stride - g.pad + kh, iw = ow * g.stride - g.pad + kw;
+        if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+          v = *reinterpret_cast<const float4*>(x + (((long long)img * g.H + ih) * g.W + iw) * g.C + c0 + c4);
+      } else {
+        if (c0 + c4 < ncols) v = *reinterpret_cast<const float4*>(x + (long long)m * ld + c0 + c4);
+      }
+    }
+    tile[mrow][c4] = v.x; tile[mrow][c4 + 1] = v.y; tile[mrow][c4 + 2] = v.z; tile[mrow][c4 + 3] = v.w;
+  }
+  __syncthreads();
+  {  // store: thread (q, parity, quad) writes 4 consecutive m of output row 2q + parity
+    const int quad = tid & 7, parity = (tid >> 3) & 1, q = tid >> 4;
+    const int c = 2 * q + parity;
+    const long long row = (IM2COL ? (long long)tap * g.C : 0) + c0 + c;
+    unsigned short h[4], mm[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3_bf16(tile[quad * 4 + j][c], h[j], mm[j], l[j]);
+    const long long off = plane_offset(row, m0 + quad * 4, Kpad / 32, 1);
+    *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)mm[0] | ((unsigned)mm[1] << 16), (unsigned)mm[2] | ((unsigned)mm[3] << 16));
+    *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+
+size_t conv_wgrad_bf3_plane_elems(const ConvDesc& d, int which) {     // which: 0 = dY^T planes, 1 = patch^T planes
+  const size_t kpad = ((size_t)d.M() + 31) / 32 * 32;
+  const size_t rows = which == 0 ? (size_t)d.CO : (size_t)d.K();
+  return ((rows + 1) & ~(size_t)1) * kpad;
+}
+size_t conv_wgrad_bf3_ws_floats(const ConvDesc& d, int splitk) {
+  return (size_t)ceil_div(d.CO, 64) * ceil_div(d.K(), 64) * splitk * 64 * 64;
+}
+
+int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk,
+                   unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st) {
+  DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.CO % 32 == 0, "conv_wgrad_bf3: NHWC input, C and CO %% 32");
+  const int M = d.M(), Kpad = (M + 31) / 32 * 32;
+  const ConvGeom g = d.geom();
+  hipLaunchKernelGGL((transpose_split_kernel<false>), dim3(Kpad / 32, d.CO / 32), dim3(256), 0, st, dy, (long long)d.CO, M,
+                     Kpad, d.CO, g, dyT[0], dyT[1], dyT[2]);
+  hipLaunchKernelGGL((transpose_split_kernel<true>), dim3(Kpad / 32, d.KH * d.KW * (d.C / 32)), dim3(256), 0, st, x,
+                     (long long)d.C, M, Kpad, d.C, g, pT[0], pT[1], pT[2]);
+  DIC_LAUNCH_CHECK();
+  Bf3Params p{};
+  p.M = d.CO; p.N = d.K(); p.K = Kpad;
+  for (int i = 0; i < 3; ++i) { p.A.p[i] = dyT[i]; p.B.p[i] = pT[i]; }
+  p.A.kind = OPK_ROWK; p.A.ld = Kpad; p.A.paired = 1;
+  p.B.kind = OPK_ROWK; p.B.ld = Kpad; p.B.paired = 1;
+  p.ep = ep_store(dw_ohwi, d.K(), nullptr, ACT_NONE);
+  return launch_bf3(p, st, nullptr, splitk, ws);
 }
 
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
