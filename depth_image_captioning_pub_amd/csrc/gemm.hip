@@ -32,14 +32,16 @@ struct Loader {
   int R, K, vec;
   ConvGeom g;
   int kc, i4, kk0, gi;
+  const int* ktab;           // GATHER: LDS table k -> (input offset | kh << 20 | kw << 26), or null (see gather_table)
   bool valid[NV];
   long long base[NV];
+  long long gbase[NV];       // GATHER table path: element offset of (image, ih0, iw0, channel 0)
   int ih0[NV], iw0[NV];
   int jkh[4], jkw[4], jc[4];
   bool jvalid[4];
 
   __device__ __forceinline__ void init(const GemmOperand& op, int r0, int R_, int K_) {
-    p = op.p; ld = op.ld; R = R_; K = K_; vec = op.vec; g = op.g;
+    p = op.p; ld = op.ld; R = R_; K = K_; vec = op.vec; g = op.g; ktab = nullptr;
     const int tid = threadIdx.x;
     if constexpr (KFAST) {
       kc = tid & 7;
@@ -56,6 +58,8 @@ struct Loader {
           ih0[r] = oh * g.stride - g.pad;
           iw0[r] = ow * g.stride - g.pad;
           base[r] = (KIND == OPK_IM2COL) ? (long long)img * g.H * g.W * g.C : (long long)img;
+          gbase[r] = g.nchw ? (long long)img * g.C * g.H * g.W + (long long)ih0[r] * g.W + iw0[r]
+                            : (((long long)img * g.H + ih0[r]) * g.W + iw0[r]) * g.C;
         }
       }
     } else {
@@ -114,6 +118,13 @@ struct Loader {
         for (int j = 0; j < 4; ++j) {
           const int k = k0 + kc * 4 + j;
           float x = 0.f;
+          if (ktab) {       // table path: no integer divisions per element (they made the 7x7 stems VALU-bound)
+            if (valid[r] && k < K) {
+              const int e = ktab[k];
+              const int ih = ih0[r] + ((e >> 20) & 63), iw = iw0[r] + ((e >> 26) & 63);
+              if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W) x = p[gbase[r] + (e & 0xfffff)];
+            }
+          } else
           if (valid[r] && k < K) {
             const int kpos = k / g.C, c = k - kpos * g.C;
             const int kh = kpos / g.KW, kw = kpos - kh * g.KW;
@@ -514,6 +525,21 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   LB lbld;
   la.init(p.A, tm * BM, p.M, p.K);
   lbld.init(p.B, tn * BN, p.N, p.K);
+  if constexpr (AK == OPK_GATHER) {
+    // k -> (kh, kw, c) decomposition once per workgroup instead of two integer divisions per gathered element
+    __shared__ int ktab[256];
+    const ConvGeom& g = p.A.g;
+    if (p.K <= 256 && (long long)g.C * g.H * g.W < (1 << 20) && g.KH < 64 && g.KW < 64) {
+      if (tid < p.K) {
+        const int kpos = tid / g.C, c = tid - kpos * g.C;
+        const int kh = kpos / g.KW, kw = kpos - kh * g.KW;
+        const int off = g.nchw ? (c * g.H + kh) * g.W + kw : (kh * g.W + kw) * g.C + c;
+        ktab[tid] = off | (kh << 20) | (kw << 26);
+      }
+      __syncthreads();
+      la.ktab = ktab;
+    }
+  }
 
   const int nk = (p.K + BK - 1) / BK;
   const int kt0 = z * p.ktiles_per_split;

@@ -339,6 +339,7 @@ static int g_bf3_force = 0;     // benchmarking: 11 / 21 / 22 force the 64x64 / 
 void gemm_bf3_force_tile(int code);
 
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
+static int g_bf3_tail_mode = 0; // benchmarking (codes 60..63): 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 template <int AK, int TM, int TN>
 static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
@@ -352,6 +353,7 @@ void gemm_bf3_force_tile(int code) {
   if (code == 42) { g_bf3_stages = 2; return; }
   if (code == 43) { g_bf3_stages = 3; return; }
   if (code >= 50 && code <= 52) { g_bf3_ablate = code - 50; return; }
+  if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return; }
   g_bf3_force = code;
 }
 
@@ -387,11 +389,11 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     tail_tiles = T2; p.tail_first_tile = 0; p.tail_first_block = 0; p.tail_split = splitk; p.tail_ws = splitk_ws;
     total = T2 * splitk;
   } else
-  if (tail_ws && tmv == 1 && tnv == 1) {
+  if (tail_ws && tmv == 1 && tnv == 1 && g_bf3_tail_mode != 1) {
     const int r = T % 256;
     int sp = r > 0 ? 256 / r : 0;
-    sp = std::min(sp, std::min(nk / 2, 16));
-    if (r > 0 && r <= 128 && sp >= 2 && T < 7 * 256) {
+    sp = std::min(sp, std::min(nk / 2, g_bf3_tail_mode == 3 ? 4 : 16));
+    if (r > 0 && r <= 128 && sp >= 2 && (T < 7 * 256 || g_bf3_tail_mode == 2)) {
       tail_tiles = r; p.tail_first_tile = T - r; p.tail_first_block = T - r; p.tail_split = sp; p.tail_ws = tail_ws;
       total = (T - r) + r * sp;
     }
