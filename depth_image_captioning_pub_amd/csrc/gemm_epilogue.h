@@ -37,7 +37,7 @@ __device__ __forceinline__ void gemm_epilogue(const P& p, f32x16 (&acc)[BM / 64]
   // Fast path (every convolution tile that lies inside the matrix): plain store (+ per-column bias), straight-line
   // code with one row pointer per register group.  The generic per-element path below is ~1700 instructions per tile
   // and dominated the short-K launches (K = 64: 137 us with it, 40 us without any epilogue).
-  const bool fast = p.splitk == 1 && !p.ep.row_map && !p.ep.C2 && !p.ep.accumulate && p.ep.act == ACT_NONE &&
+  const bool fast = p.splitk == 1 && !p.ep.row_map && !p.ep.C2 && p.ep.act == ACT_NONE &&
                     p.ep.alpha == 1.0f && (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
   if (fast) {
 #pragma unroll
@@ -47,9 +47,17 @@ __device__ __forceinline__ void gemm_epilogue(const P& p, f32x16 (&acc)[BM / 64]
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n;
+        float old[16];
+        if (p.ep.accumulate) {          // C += result: all 16 old values in flight before the first store
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = acc[i][j][r] + b;
+          const float v = acc[i][j][r] + b + old[r];
           col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = v;
           cs[j] += v;
           cs2[j] += v * v;
