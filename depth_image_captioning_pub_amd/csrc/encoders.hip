@@ -194,13 +194,21 @@ static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
+static int g_fused_tail_bn = 1;     // benchmarking (codes 120/121): 0 = separate tail fix-up and BN finalize launches
+void resnet_debug_fused_tail_bn(int on) { g_fused_tail_bn = on; }
+
 // conv (bf16x3 planes in, raw fp32 out) -> BN scale/shift
 static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, const dic_conv_bn_layer& L, float* y,
                        const RnWs& ws, int train_bn, hipStream_t st) {
   int mtiles = 0;
   const unsigned short* xp[3] = {x_planes[0], x_planes[1], x_planes[2]};
   const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
-  DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st));
+  int fused = 0;
+  const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, ws.bn.scale, ws.bn.shift, ws.bn.mean, ws.bn.invstd,
+                      (double)d.M(), kBnEps, kBnMomentum};
+  DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st, nullptr,
+                       (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused));
+  if (train_bn && fused) return DIC_OK;        // statistics were finalized inside the tail fix-up launch
   if (train_bn)
     return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, ws.bn,
                              ws.red, st);

@@ -91,6 +91,20 @@ GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
 void gemm_force_v1(int on);
 void gemm_bf3_force_tile(int code);
 int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st);
+
+// Train-mode BatchNorm finalize fused into the tail fix-up launch (saves one dependent dispatch per tail-split
+// convolution): extra workgroups reduce the tile partials of 32 channels each; for the remainder tiles they recompute
+// the statistics from the K slices themselves, so they do not depend on the fix-up workgroups of the same launch.
+struct BnFuseArgs {
+  const float *gamma, *beta;
+  float *running_mean, *running_var;      // nullable
+  float *scale, *shift, *mean, *invstd;   // outputs (BnBuf)
+  double count;                           // rows of the activation (B*OH*OW)
+  float eps, momentum;
+};
+// requires p.ep.stats, tail tiles aligned to whole tile rows (tail_first_tile % ntiles == 0), no bias / activation.
+bool gemm_tail_fixup_bn_eligible(const GemmParams& p, int tail_tiles);
+int gemm_launch_tail_fixup_bn(const GemmParams& p, int tail_tiles, const BnFuseArgs& bn, hipStream_t st);
 void gemm_profile_mark_begin(hipStream_t st, double flops, int key);
 void gemm_profile_mark_end(hipStream_t st);
 int gemm_profile_begin();

@@ -455,14 +455,13 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(const GemmParams p) {
 // all of its (<= 16) slice loads before the first add, which makes the kernel one memory round trip deep.
 constexpr int kTailMaxSplit = 16;
 template <int NS>      // NS = slice loads issued per thread (2/4/8/16 >= tail_split; the surplus re-reads the last slice)
-__global__ void __launch_bounds__(1024) tail_fixup_kernel(const GemmParams p) {
+__device__ __forceinline__ void tail_fixup_tile(const GemmParams& p, const int tail_index, float4 (*sred)[64][16],
+                                                float4 (*sred2)[8][16]) {
   constexpr int BM = 64, BN = 64;
-  __shared__ float4 sred[2][64][16];
-  __shared__ float4 sred2[2][8][16];
-  const int t = p.tail_first_tile + blockIdx.x;
+  const int t = p.tail_first_tile + tail_index;
   const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
   const int c4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-  const float* base = p.tail_ws + (long long)blockIdx.x * p.tail_split * BM * BN + row * BN + c4 * 4;
+  const float* base = p.tail_ws + (long long)tail_index * p.tail_split * BM * BN + row * BN + c4 * 4;
   float4 x[NS];
 #pragma unroll
   for (int u = 0; u < NS; ++u) {     // branch-free guard: clamped slice, zeroed afterwards
@@ -501,6 +500,97 @@ __global__ void __launch_bounds__(1024) tail_fixup_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (n + j < p.N) p.ep.stats[((long long)tm * 2 + row) * p.N + n + j] = r[j];
+    }
+  }
+}
+
+template <int NS>
+__global__ void __launch_bounds__(1024) tail_fixup_kernel(const GemmParams p) {
+  __shared__ float4 sred[2][64][16];
+  __shared__ float4 sred2[2][8][16];
+  tail_fixup_tile<NS>(p, blockIdx.x, sred, sred2);
+}
+
+// Fix-up + BatchNorm finalize in one launch.  Workgroups [0, tail_tiles): the fix-up above.  Workgroups beyond: one
+// per 32 channels; 1024 threads = 32 channels x 32 lanes.  Regular tile rows come from the partial table (fp64, lane-
+// strided, all of a thread's loads in flight); the remainder tile rows are re-derived from the K slices (same slice
+// order as the fix-up, so the same values), each lane taking rows lane and lane+32 of every remainder tile row.
+template <int NS>
+__global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p, const int tail_tiles, const BnFuseArgs bn) {
+  __shared__ float4 sred[2][64][16];
+  __shared__ float4 sred2[2][8][16];
+  if ((int)blockIdx.x < tail_tiles) {
+    tail_fixup_tile<NS>(p, blockIdx.x, sred, sred2);
+    return;
+  }
+  double(*s1)[33] = reinterpret_cast<double(*)[33]>(&sred[0][0][0]);          // [32][33] doubles = 8448 B each
+  double(*s2)[33] = reinterpret_cast<double(*)[33]>(&sred[1][0][0]);
+  const int C = p.N;
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = ((int)blockIdx.x - tail_tiles) * 32 + cl;
+  const int mt_reg = p.tail_first_tile / p.ntiles;                            // tile rows finished by the main kernel
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int t = g; t < mt_reg; t += 32 * 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int tt = t + u * 32;
+        const int tc = min(tt, mt_reg - 1);        // branch-free guard
+        const float xa = p.ep.stats[((long long)tc * 2 + 0) * C + c], xb = p.ep.stats[((long long)tc * 2 + 1) * C + c];
+        va[u] = tt < mt_reg ? xa : 0.f;
+        vb[u] = tt < mt_reg ? xb : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
+    }
+    // remainder tile rows: value = sum of the K slices (slice order), statistics straight in fp64
+    const int tn = c >> 6, col = c & 63;
+    for (int tm = mt_reg; tm < p.mtiles; ++tm) {
+      const long long q = (long long)(tm - mt_reg) * p.ntiles + tn;            // index among the remainder tiles
+      const float* base = p.tail_ws + q * p.tail_split * 4096 + col;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = g + 32 * rr;
+        float x[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          x[u] = base[(long long)min(u, p.tail_split - 1) * 4096 + row * 64];
+          if (u >= p.tail_split) x[u] = 0.f;
+        }
+        float v = x[0];
+#pragma unroll
+        for (int u = 1; u < NS; ++u) v += x[u];
+        if (tm * 64 + row < p.M) { a += (double)v; b += (double)v * (double)v; }
+      }
+    }
+  }
+  s1[g][cl] = a; s2[g][cl] = b;
+  __syncthreads();
+  if (g < 4) {
+    a = 0.0; b = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a += s1[g * 8 + i][cl]; b += s2[g * 8 + i][cl]; }
+  }
+  __syncthreads();
+  if (g < 4) { s1[g][cl] = a; s2[g][cl] = b; }
+  __syncthreads();
+  if (g == 0 && c < C) {
+    a = (s1[0][cl] + s1[1][cl]) + (s1[2][cl] + s1[3][cl]);
+    b = (s2[0][cl] + s2[1][cl]) + (s2[2][cl] + s2[3][cl]);
+    const double mean = a / bn.count;
+    double var = b / bn.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = 1.0f / sqrtf((float)var + bn.eps);
+    const float sc = bn.gamma[c] * invstd;
+    bn.scale[c] = sc;
+    bn.shift[c] = bn.beta[c] - (float)mean * sc;
+    bn.mean[c] = (float)mean;
+    bn.invstd[c] = invstd;
+    if (bn.running_mean) {
+      const double unb = bn.count > 1.0 ? var * bn.count / (bn.count - 1.0) : var;
+      bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
+      bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unb;
     }
   }
 }
@@ -777,6 +867,22 @@ int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st) 
   else if (p.tail_split <= 4) hipLaunchKernelGGL(tail_fixup_kernel<4>, g, b, 0, st, p);
   else if (p.tail_split <= 8) hipLaunchKernelGGL(tail_fixup_kernel<8>, g, b, 0, st, p);
   else hipLaunchKernelGGL(tail_fixup_kernel<16>, g, b, 0, st, p);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+bool gemm_tail_fixup_bn_eligible(const GemmParams& p, int tail_tiles) {
+  return tail_tiles > 0 && p.ep.stats != nullptr && p.tail_first_tile % p.ntiles == 0 && p.ep.bias == nullptr &&
+         p.ep.act == ACT_NONE && !p.ep.accumulate && !p.ep.row_map && !p.ep.C2 && p.N % 32 == 0 &&
+         p.mtiles <= 512;     // (larger layers use the two-stage finalize)
+}
+
+int gemm_launch_tail_fixup_bn(const GemmParams& p, int tail_tiles, const BnFuseArgs& bn, hipStream_t st) {
+  const dim3 g(tail_tiles + p.N / 32), b(1024);
+  if (p.tail_split <= 2) hipLaunchKernelGGL(tail_fixup_bn_kernel<2>, g, b, 0, st, p, tail_tiles, bn);
+  else if (p.tail_split <= 4) hipLaunchKernelGGL(tail_fixup_bn_kernel<4>, g, b, 0, st, p, tail_tiles, bn);
+  else if (p.tail_split <= 8) hipLaunchKernelGGL(tail_fixup_bn_kernel<8>, g, b, 0, st, p, tail_tiles, bn);
+  else hipLaunchKernelGGL(tail_fixup_bn_kernel<16>, g, b, 0, st, p, tail_tiles, bn);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

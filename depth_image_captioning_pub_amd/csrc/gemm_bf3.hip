@@ -357,7 +357,8 @@ void gemm_bf3_force_tile(int code) {
   g_bf3_force = code;
 }
 
-static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 1, float* splitk_ws = nullptr) {
+static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 1, float* splitk_ws = nullptr,
+                      const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr) {
   // tile choice (measured, scripts/bench_bf3.py): bigger per-wave tiles halve the LDS fragment traffic per MFMA and
   // amortise the per-K-tile barrier, but need >= ~2 workgroups per CU to keep 256 CUs busy
   int tmv = 1, tnv = 1;
@@ -411,14 +412,20 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     GemmParams g{};
     g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.ep.alpha = 1.0f; g.mtiles = p.mtiles; g.ntiles = p.ntiles;
     g.tail_first_tile = p.tail_first_tile; g.tail_split = p.tail_split; g.tail_ws = p.tail_ws;
-    DIC_TRY(gemm_launch_tail_fixup(g, tail_tiles, st));
+    if (bn_fuse && gemm_tail_fixup_bn_eligible(g, tail_tiles)) {      // fix-up + BatchNorm finalize in one launch
+      DIC_TRY(gemm_launch_tail_fixup_bn(g, tail_tiles, *bn_fuse, st));
+      if (bn_fused) *bn_fused = 1;
+    } else {
+      DIC_TRY(gemm_launch_tail_fixup(g, tail_tiles, st));
+    }
   }
   return DIC_OK;
 }
 
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
-                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias) {
+                 float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias,
+                 const BnFuseArgs* bn_fuse, int* bn_fused) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
   Bf3Params p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -428,7 +435,8 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.B.kind = OPK_ROWK; p.B.ld = d.K(); p.B.paired = 1;
   p.ep = ep_store(y, d.CO, bias, ACT_NONE);
   p.ep.stats = bn_partial;
-  DIC_TRY(launch_bf3(p, st, tail_ws));
+  if (bn_fused) *bn_fused = 0;
+  DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
   return DIC_OK;
 }
@@ -523,7 +531,7 @@ int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& 
   DIC_REQUIRE(d.stride == 1 && d.CO % 32 == 0, "conv_dgrad_s1_bf3: stride 1, CO %% 32");
   // full correlation of dY (an [OH,OW,CO] image) with the flipped kernel, padding KH-1-pad
   const ConvDesc dd{d.B, d.OH(), d.OW(), d.CO, d.C, d.KH, d.KW, 1, d.KH - 1 - d.pad, 0};
-  return conv_fwd_bf3(dy_planes, dd, wflip_planes, dx, nullptr, nullptr, nullptr, st, nullptr);
+  return conv_fwd_bf3(dy_planes, dd, wflip_planes, dx, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr);
 }
 
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
