@@ -62,8 +62,11 @@ def profile_step(trainer, args_step):
     for i in range(nout.value):
         k = keys[i]
         if k >= 2000:                                   # split-bf16 convolution kernel (gemm_bf3.hip)
-            a = (k - 2000) // 10
-            rows.append({"kernel": f"gemm_bf3_kernel<{KIND_NAMES[a]}>", "rocprof_name": f"gemm_bf3_kernel<{a}, 1, 1, 2, 0>",
+            a, tcode = (k - 2000) // 10, (k - 2000) % 10
+            tm, tn = 1 + tcode // 2, 1 + tcode % 2          # workgroup tile 64*tm x 64*tn
+            tile = "" if (tm, tn) == (1, 1) else f",{64 * tm}x{64 * tn}"
+            rows.append({"kernel": f"gemm_bf3_kernel<{KIND_NAMES[a]}{tile}>",
+                         "rocprof_name": f"gemm_bf3_kernel<{a}, {tm}, {tn}, 2, 0>",
                          "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "peak": PEAK_BF16X3_TFLOPS})
             continue
         dma = k >= 1000
