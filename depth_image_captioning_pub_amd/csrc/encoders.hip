@@ -334,8 +334,8 @@ int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth
   DIC_TRY(conv_flip_weights(w->conv3_w, g.c3, ws.w3f, st));
   DIC_TRY(conv_dgrad_s1(ws.dy3, g.c3, ws.w3f, ws.dy2p, st));
   // layer 2
-  DIC_TRY(maxpool_relu_bwd(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, ws.bn2, ws.dy2, st));
-  DIC_TRY(bn_backward(ws.dy2, ws.x2, g.M2, 512, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b, ws.bn_ws, st));
+  DIC_TRY(bn_pool_backward(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b,
+                           ws.bn_ws, ws.dy2, st));
   DIC_TRY(conv_wgrad_bf3(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));
   DIC_TRY(ohwi_to_oihw(ws.dw2o, gr->conv2_w, 512, 128, 3, 3, st));
   DIC_TRY(colsum_rows(ws.dy2, 512, g.M2, 512, gr->conv2_b, ws.cs_ws, st));
@@ -348,8 +348,8 @@ int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth
     DIC_TRY(conv_dgrad_s1_bf3(dp, g.c2, wp, ws.dy1p, st));
   }
   // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
-  DIC_TRY(maxpool_relu_bwd(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, ws.bn1, ws.dy1, st));
-  DIC_TRY(bn_backward(ws.dy1, ws.x1, g.M1, 128, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b, ws.bn_ws, st));
+  DIC_TRY(bn_pool_backward(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,
+                           ws.bn_ws, ws.dy1, st));
   DIC_TRY(conv_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, kWg1Split, ws.wg_ws, st)); // C_in = 1: OHWI == OIHW
   DIC_TRY(colsum_rows(ws.dy1, 128, g.M1, 128, gr->conv1_b, ws.cs_ws, st));
   return DIC_OK;

@@ -575,6 +575,129 @@ int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float
   return DIC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Max-pool + ReLU + BatchNorm backward without materialising the (8/9 zero) pooled gradient: the gradient that
+// reaches position (b,h,w,c) of the pre-pool tensor is dpool[window] if this position was the window's argmax and
+// the BN output was positive, else 0 (non-overlapping k x k windows) - recomputed on the fly in both BN-backward
+// passes.  Versus maxpool_relu_bwd + bn_backward this drops one write and two reads of the full-size tensor
+// (layer 1: 175 MB each).
+// ------------------------------------------------------------------------------------------
+struct PoolGeom { int H, W, k, PH, PW; };
+
+__device__ __forceinline__ float4 pool_relu_grad4(const float* __restrict__ dpool, const unsigned char* __restrict__ idx,
+                                                  const float4 v, const float4 sc, const float4 sh, long long row,
+                                                  int c4, int C4, PoolGeom pg) {
+  const int w = (int)(row % pg.W);
+  const long long r2 = row / pg.W;
+  const int h = (int)(r2 % pg.H);
+  const long long b = r2 / pg.H;
+  const int ph = h / pg.k, pw = w / pg.k;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ph < pg.PH && pw < pg.PW) {
+    const long long po = ((b * pg.PH + ph) * pg.PW + pw) * C4 + c4;
+    const float4 d = reinterpret_cast<const float4*>(dpool)[po];
+    const uchar4 id = reinterpret_cast<const uchar4*>(idx)[po];
+    const unsigned char me = (unsigned char)((h - ph * pg.k) * pg.k + (w - pw * pg.k));
+    g.x = (id.x == me && v.x * sc.x + sh.x > 0.f) ? d.x : 0.f;
+    g.y = (id.y == me && v.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+    g.z = (id.z == me && v.z * sc.z + sh.z > 0.f) ? d.z : 0.f;
+    g.w = (id.w == me && v.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+  }
+  return g;
+}
+
+__global__ void __launch_bounds__(256) bn_pool_bwd_reduce_kernel(const float* __restrict__ dpool,
+                                                                  const unsigned char* __restrict__ idx,
+                                                                  const float* __restrict__ x, long long rows, int C,
+                                                                  PoolGeom pg, BnBuf bn, float* __restrict__ part) {
+  __shared__ float4 sa[16][16], sb[16][16];
+  const int c4l = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4l * 4;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * per, r1 = min(rows, r0 + per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (c < C) {
+    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
+    const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
+    for (long long r = r0 + rl; r < r1; r += 64) {        // 4 rows in flight per thread
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + min(r + 16 * u, r1 - 1) * C + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long rr = r + 16 * u;
+        if (rr < r1) {
+          const float4 g = pool_relu_grad4(dpool, idx, v[u], sc, sh, rr, c >> 2, C >> 2, pg);
+          a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+          b.x += g.x * (v[u].x - mu.x) * is.x; b.y += g.y * (v[u].y - mu.y) * is.y;
+          b.z += g.z * (v[u].z - mu.z) * is.z; b.w += g.w * (v[u].w - mu.w) * is.w;
+        }
+      }
+    }
+  }
+  sa[rl][c4l] = a; sb[rl][c4l] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      a.x += sa[i][c4l].x; a.y += sa[i][c4l].y; a.z += sa[i][c4l].z; a.w += sa[i][c4l].w;
+      b.x += sb[i][c4l].x; b.y += sb[i][c4l].y; b.z += sb[i][c4l].z; b.w += sb[i][c4l].w;
+    }
+    *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * 2 + 0) * C + c) = a;
+    *reinterpret_cast<float4*>(part + ((long long)blockIdx.y * 2 + 1) * C + c) = b;
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __restrict__ dpool,
+                                                                 const unsigned char* __restrict__ idx,
+                                                                 const float* __restrict__ x, float* __restrict__ dy,
+                                                                 long long n4, int C4, PoolGeom pg,
+                                                                 const float* __restrict__ gamma, BnBuf bn,
+                                                                 const float* __restrict__ k2,
+                                                                 const float* __restrict__ k3) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const int c4 = (int)(i % C4), c = c4 * 4;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
+    const float4 g = pool_relu_grad4(dpool, idx, v, sc, sh, i / C4, c4, C4, pg);
+    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 a2 = *reinterpret_cast<const float4*>(k2 + c);
+    const float4 a3 = *reinterpret_cast<const float4*>(k3 + c);
+    float4 o;
+    o.x = ga.x * is.x * (g.x - a2.x - (v.x - mu.x) * is.x * a3.x);
+    o.y = ga.y * is.y * (g.y - a2.y - (v.y - mu.y) * is.y * a3.y);
+    o.z = ga.z * is.z * (g.z - a2.z - (v.z - mu.z) * is.z * a3.z);
+    o.w = ga.w * is.w * (g.w - a2.w - (v.w - mu.w) * is.w * a3.w);
+    reinterpret_cast<float4*>(dy)[i] = o;
+  }
+}
+
+int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
+                     const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st) {
+  DIC_REQUIRE(C % 64 == 0, "bn_pool_backward: C %% 64");
+  const long long rows = (long long)B * H * W;
+  const PoolGeom pg{H, W, k, H / k, W / k};
+  float* part = ws;
+  float* k2 = ws + (size_t)kBnChunksMax * 2 * C;
+  float* k3 = k2 + C;
+  const int chunks = reduce_chunks(C);
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(C / 64, chunks), dim3(256), 0, st, dpool, idx, x, rows, C, pg, bn,
+                     part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, chunks, C, (double)rows,
+                     dgamma, dbeta, k2, k3);
+  const long long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dpool, idx, x, dy, n4, C / 4, pg,
+                     gamma, bn, k2, k3);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
 // column sums with a fixed two-stage tree (deterministic).  Stage 1: block = 64 channels (16 float4 lanes) x 16 row
 // lanes over one of 64 row chunks -> ws[chunk][C]; stage 2 sums the 64 chunk rows.  (C % 4 == 0; else scalar path)
 __global__ void __launch_bounds__(256) colsum_rows_v4_kernel(const float* __restrict__ X, long long ld, long long rows,
