@@ -367,6 +367,9 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // optionally (policy 31), on the 3-tiles-per-CU shapes of ResNet layer 3 (M=12544, N=256).
   const long long t11 = (long long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
   if (t11 >= 16384 && p.K >= 1024) { tmv = 2; tnv = 1; }
+  // batch-256-scale grids (scripts/bench_bf3_b256.py): 128x64 wins by 4..16 % except on the narrow shallow shapes
+  // (N <= 256 and K <= 1024); neutral at batch 64, +1.2 % on the batch-256 step
+  if (t11 >= 6144 && !(p.N <= 256 && p.K <= 1024)) { tmv = 2; tnv = 1; }
   // 512..1023 tiles of 64x64 (ResNet layer 3 at batch 64: 784 = one round of 768 + a 16-tile remainder that needs the
   // K-split + fix-up): 128x64 tiles make it a single round of 392 workgroups at two per CU.  Measured on the whole
   // ResNet forward (scripts/bench_resnet_ab.py 11 20): 15.39 -> 15.18 ms.
