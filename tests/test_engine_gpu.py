@@ -130,3 +130,34 @@ def test_full_pipeline_step_runs_and_learns(lib):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.3, losses
     ev = float(tr.eval_loss(imgs, depth, caps, lens).item())
     assert np.isfinite(ev)
+
+
+@pytest.mark.parametrize("conv_mode", ["fp32", "bf16x3"])
+def test_prefetch_graph_replay_equals_eager(lib, conv_mode):
+    """engine.prefetch_features replays the frozen ResNet forward from a captured hipGraph: the features of every
+    batch and the BatchNorm running statistics (updated once per batch, in batch order - quirk Q1) must be bit-identical
+    to eager launches, for the capture call (eager + capture) as well as for replays, on both output buffers."""
+    B, size = 2, 64
+    batches = [syn.rgb_images(B, seed=80 + i, size=size).to(DEV) for i in range(5)]
+
+    def run(use_graph):
+        tr = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode=conv_mode)
+        tr.use_graph = use_graph
+        feats = []
+        for x in batches:
+            tr.prefetch_features(x)
+            _, f, done = tr.prefetched
+            done.synchronize()
+            feats.append(f.clone())
+        torch.cuda.synchronize()
+        stats = {k: v.clone() for k, v in tr.rn_w.items() if "running" in k}
+        return feats, stats, tr
+
+    f_g, s_g, tr_g = run(True)
+    f_e, s_e, _ = run(False)
+    assert tr_g.use_graph and len(tr_g.rn_graphs) == 2, tr_g.last.get("resnet_graph_error")     # both buffers captured
+    for i, (a, b) in enumerate(zip(f_g, f_e)):
+        assert torch.equal(a, b), f"batch {i}"
+    assert s_g.keys() == s_e.keys() and len(s_g) > 0
+    for k in s_g:
+        assert torch.equal(s_g[k], s_e[k]), k
