@@ -11,6 +11,7 @@ constexpr int kG = 4 * kH;              // LSTM gate rows (i,f,g,o)
 constexpr int kXK = kE + kD + kH;       // K of the fused LSTM GEMM: [embedding | gate*ctx | h_prev]
 constexpr int kNCH = kD / 256;          // D chunks of 256 channels per workgroup (attention kernels)
 constexpr int kLCH = 4;                 // L chunks of 49 cells (score-backward kernel)
+constexpr int kLc = 49;                 // distinct cells when the 14x14 grid is a 2x2 replication of a 7x7 map (Q3)
 constexpr int kS_LSTM = 18;             // split-K of the per-step LSTM gate GEMM (72 K tiles -> 4 per workgroup)
 constexpr int kS_DX = 4;                // split-K of the per-step dX GEMM (16 K tiles)
 
@@ -22,6 +23,7 @@ struct DecoderWs {
   // backward
   float *dHd, *dG, *slab_dx, *dctx, *dgpre, *dq, *dalp, *pbeta, *dqp, *dwf_acc, *dbf_acc, *dPacc, *carry_dc;
   float *dinit, *dmean, *colsum_ws;
+  float *alpha_c, *dalpha_c;     // compact (49-cell) mode: group softmax [B,T,49] and its incoming gradient
   int* dlen;
   float* logits_step;
   long long* ids;

@@ -62,6 +62,8 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.dinit = c.take<float>((size_t)B * 2 * kH);
   w.dmean = c.take<float>((size_t)B * kD);
   w.colsum_ws = c.take<float>((size_t)64 * std::max(std::max(V, kD), kXK));
+  w.alpha_c = c.take<float>(BT * kLc);
+  w.dalpha_c = c.take<float>(BT * kLc);
   w.dlen = c.take<int>((size_t)B);
   w.logits_step = c.take<float>((size_t)B * V);
   w.ids = c.take<long long>((size_t)B);
@@ -125,13 +127,14 @@ static int colsum(const float* X, long long ld, int M, int N, float* out, float*
 
 // F = F_rgb + F_depth ; mean[b,d] = sum_l F[b,l,d] / L          (depth_models.py:163,166)
 // grid (D/256, B), 256 threads: wave w takes l = w, w+4, ...; lanes hold float4 over 256 channels
+template <int L>
 __global__ void __launch_bounds__(256) fuse_mean_kernel(const float* __restrict__ frgb, const float* __restrict__ fdep,
                                                          float* __restrict__ F, float* __restrict__ mean) {
   __shared__ float4 red[4][64];
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long base = (long long)b * kL * kD + blockIdx.x * 256 + lane * 4;
+  const long long base = (long long)b * L * kD + blockIdx.x * 256 + lane * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int l = w; l < kL; l += 4) {
+  for (int l = w; l < L; l += 4) {
     const long long o = base + (long long)l * kD;
     float4 v = *reinterpret_cast<const float4*>(frgb + o);
     if (fdep) {
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(256) fuse_mean_kernel(const float* __restrict_
     float4 s = red[0][lane];
 #pragma unroll
     for (int i = 1; i < 4; ++i) { s.x += red[i][lane].x; s.y += red[i][lane].y; s.z += red[i][lane].z; s.w += red[i][lane].w; }
-    const float inv = (float)kL;
+    const float inv = (float)L;
     s.x /= inv; s.y /= inv; s.z /= inv; s.w /= inv;
     *reinterpret_cast<float4*>(mean + (long long)b * kD + blockIdx.x * 256 + lane * 4) = s;
   }
@@ -173,6 +176,7 @@ __global__ void __launch_bounds__(128) embed_gather_kernel(const float* __restri
 // row; the HBM-heavy part - one pass over F[b,:,chunk] - is split between them.
 // mode 0: softmax(e); 1: softmax((e+g)/temp); 2: one-hot(argmax(e+g)), g = -log(-log(u)).
 // ------------------------------------------------------------------------------------------
+template <int L>
 __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float* __restrict__ F, const float* __restrict__ P, const float* __restrict__ Hall,
     const float* __restrict__ WhT, const float* __restrict__ b_h, const float* __restrict__ w_full,
@@ -184,7 +188,10 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   // one memory round trip deep): q 32 loads/thread, scores 13 x 16 B, context + gate 2 x (13 x 16 B + 32 x 4 B).
   __shared__ float h_s[kH];
   __shared__ float q_s[4][kA];
-  __shared__ float e_s[208];
+  constexpr int NPS = (L + 15) / 16;                 // score passes: 16 cells (half-waves) per pass
+  constexpr int NB = ((L + 7) / 8 + 1) / 2;          // context loop: two batches of NB cells per wave (8 waves)
+  constexpr int EP = 16 * NB;                        // padded cell count of the context loop
+  __shared__ float e_s[EP];
   __shared__ float red_s[16];
   __shared__ __align__(16) float cred[8][256];
   __shared__ float gp_s[2][256];
@@ -196,7 +203,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   const long long bt = (long long)b * T + t;
 
   if (tid < kH) h_s[tid] = Hall[((long long)b * (T + 1) + t) * kH + tid];
-  if (tid >= 256 && tid < 256 + 12) e_s[kL + tid - 256] = 0.f;      // padding cells of the context loop
+  if (tid >= 256 && tid < 256 + (EP - L)) e_s[L + tid - 256] = 0.f;  // padding cells of the context loop
   __syncthreads();
   {  // q = Wh h + bh   (four quarters of K per output)
     const int a = tid & (kA - 1), quarter = w >> 1;
@@ -222,29 +229,29 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float4 q4 = *reinterpret_cast<const float4*>(&q_s[0][l32 * 4]);
     const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
     const float bf = b_full[0];
-    const float* Pu = P + (long long)b * kL * kA;                       // uniform
-    float4 p4[13];
+    const float* Pu = P + (long long)b * L * kA;                       // uniform
+    float4 p4[NPS];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {      // branch-free guard: cells past the end re-read the last cell (never stored)
-      const unsigned poff = (unsigned)min(hw + 16 * i, kL - 1) * kA + l32 * 4;
+    for (int i = 0; i < NPS; ++i) {     // branch-free guard: cells past the end re-read the last cell (never stored)
+      const unsigned poff = (unsigned)min(hw + 16 * i, L - 1) * kA + l32 * 4;
       p4[i] = *reinterpret_cast<const float4*>(Pu + poff);
     }
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
+    for (int i = 0; i < NPS; ++i) {
       const int l = hw + 16 * i;
       float sc = w4.x * fmaxf(p4[i].x + q4.x, 0.f) + w4.y * fmaxf(p4[i].y + q4.y, 0.f) +
                  w4.z * fmaxf(p4[i].z + q4.z, 0.f) + w4.w * fmaxf(p4[i].w + q4.w, 0.f);
       sc = half_wave_sum(sc);
-      if (l < kL && l32 == 0) e_s[l] = sc + bf;
+      if (l < L && l32 == 0) e_s[l] = sc + bf;
     }
   }
   __syncthreads();
   {  // attention weights over the 196 cells
     float z = -INFINITY;
-    if (tid < kL) {
+    if (tid < L) {
       z = e_s[tid];
       if (mode != 0) {
-        const float u = gumbel_u[((long long)t * B + b) * kL + tid];
+        const float u = gumbel_u[((long long)t * B + b) * L + tid];
         z += -logf(-logf(u));
         if (mode == 1) z /= temp;
       }
@@ -255,7 +262,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     m = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));      // cells live in waves 0..3
     float al;
     if (mode == 2) {   // first index attaining the maximum -> one-hot
-      int cand = (tid < kL && z == m) ? tid : 0x7fffffff;
+      int cand = (tid < L && z == m) ? tid : 0x7fffffff;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
       __syncthreads();
@@ -265,22 +272,22 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
                           min(__float_as_int(red_s[10]), __float_as_int(red_s[11])));
       al = (tid == win) ? 1.f : 0.f;
     } else {
-      const float ex = (tid < kL) ? expf(z - m) : 0.f;
+      const float ex = (tid < L) ? expf(z - m) : 0.f;
       const float sm = wave_sum(ex);
       if (lane == 0) red_s[8 + w] = sm;
       __syncthreads();
       al = ex / (red_s[8] + red_s[9] + red_s[10] + red_s[11]);
     }
     __syncthreads();
-    if (tid < kL) {
+    if (tid < L) {
       e_s[tid] = al;
-      if (chunk == 0) alphas[bt * kL + tid] = al;
+      if (chunk == 0) alphas[bt * L + tid] = al;
     }
   }
   __syncthreads();
   {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk (wave w takes l = w, w+8, ...), fused with the
      // pre-activation of gate = sigmoid(W_beta h + b) for the same 256 channels (two halves of K per channel)
-    const float* Fu = F + (long long)b * kL * kD + chunk * 256;                              // uniform
+    const float* Fu = F + (long long)b * L * kD + chunk * 256;                              // uniform
     const unsigned foff = lane * 4;
     const int dl = tid & 255, half = w >> 2;
     const float* Wg = WbT + (long long)(half * 64) * kD + chunk * 256 + (w & 3) * 64;           // uniform
@@ -288,11 +295,11 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     float gs = 0.f;
 #pragma unroll 1
     for (int bt2 = 0; bt2 < 2; ++bt2) {
-      float4 v[13];
+      float4 v[NB];
       float wv[32];
 #pragma unroll
-      for (int i = 0; i < 13; ++i) {
-        const int l = min(w + 8 * (bt2 * 13 + i), kL - 1);      // padding cells re-read the last cell, weight e_s = 0
+      for (int i = 0; i < NB; ++i) {
+        const int l = min(w + 8 * (bt2 * NB + i), L - 1);      // padding cells re-read the last cell, weight e_s = 0
         v[i] = *reinterpret_cast<const float4*>(Fu + (long long)l * kD + foff);
       }
       if (do_gate) {
@@ -300,8 +307,8 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
         for (int k = 0; k < 32; ++k) wv[k] = Wg[(long long)(bt2 * 32 + k) * kD + lane];
       }
 #pragma unroll
-      for (int i = 0; i < 13; ++i) {
-        const float a = e_s[w + 8 * (bt2 * 13 + i)];      // padded with zeros up to 208
+      for (int i = 0; i < NB; ++i) {
+        const float a = e_s[w + 8 * (bt2 * NB + i)];      // padded with zeros up to EP
         acc.x += a * v[i].x; acc.y += a * v[i].y; acc.z += a * v[i].z; acc.w += a * v[i].w;
       }
       if (do_gate) {
@@ -371,7 +378,7 @@ __global__ void __launch_bounds__(kH) lstm_fwd_kernel(const float* __restrict__ 
 //   final=1: only assemble the carry into dinit (gradient of h0 | c0) after step 0.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
-    int t, int T, int B, int nb_next, int have_next, int final_pass,
+    int t, int T, int B, int nb_next, int have_next, int final_pass, int nlch,
     const float* __restrict__ dHd, int packed_off, const float* __restrict__ drop,
     const float* __restrict__ slab_dx, int nslab_dx, int nb_slab, const float* __restrict__ dqp,
     const float* __restrict__ pbeta, const float* __restrict__ W_h /*[A][H]*/,
@@ -383,8 +390,7 @@ __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
   const bool carry = have_next && b < nb_next;          // row b was active at step t+1
   if (carry) {
     float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < kLCH; ++c) q += dqp[((long long)c * B + b) * kA + j];
+    for (int c = 0; c < nlch; ++c) q += dqp[((long long)c * B + b) * kA + j];
     dq_s[j] = q;
     dq_all[((long long)b * T + (t + 1)) * kA + j] = q;
   }
@@ -426,6 +432,7 @@ __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
 // the second pass over F[b,:,chunk] (d alpha partial), the W_beta^T dgpre partial for dh_{t-1},
 // and (chunk 0) the embedding-row scatter.
 // ------------------------------------------------------------------------------------------
+template <int L>
 __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
     const float* __restrict__ F, const float* __restrict__ slab_dx, int nslab, int nb, int B, int t, int T,
     const float* __restrict__ ctx_all, const float* __restrict__ gate_all, const float* __restrict__ W_beta,
@@ -469,7 +476,7 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
   const int k = tid & (kH - 1), quarter = wv_id >> 1;
   const float* Wb = W_beta + ((long long)chunk * 256 + quarter * 64) * kH + (wv_id & 1) * 64;      // uniform
   const int ln = tid & 15, grp = tid >> 4;
-  const float* Fu = F + (long long)b * kL * kD + chunk * 256;                                       // uniform
+  const float* Fu = F + (long long)b * L * kD + chunk * 256;                                       // uniform
   float4 dc4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) dc4[j] = *reinterpret_cast<const float4*>(&dctx_s[ln * 4 + 64 * j]);
@@ -485,7 +492,9 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
       const int l = grp + 32 * (part * 2 + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        v[i][j] = *reinterpret_cast<const float4*>(Fu + (unsigned)min(l, kL - 1) * kD + ln * 4 + 64 * j);   // branch-free guard
+        v[i][j] = (32 * (part * 2 + i) < L)      // (uniform: whole passes beyond the last cell are skipped)
+                      ? *reinterpret_cast<const float4*>(Fu + (unsigned)min(l, L - 1) * kD + ln * 4 + 64 * j)   // branch-free guard
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int d = 0; d < 16; ++d) ps += dgp_s[quarter * 64 + part * 16 + d] * wv[d];
@@ -504,7 +513,7 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
   __syncthreads();
   if (tid < kH)
     pbeta[((long long)chunk * B + b) * kH + tid] = (pb_s[0][tid] + pb_s[1][tid]) + (pb_s[2][tid] + pb_s[3][tid]);
-  if (tid < kL) dalp[((long long)chunk * B + b) * kL + tid] = da_s[tid];
+  if (tid < L) dalp[((long long)chunk * B + b) * L + tid] = da_s[tid];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -512,12 +521,13 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
 // 49-cell slice: dq partial, dP accumulation (P is time-invariant -> its gradient sums over steps),
 // full_att weight/bias gradient accumulators (private per (slice,row): deterministic).
 // ------------------------------------------------------------------------------------------
+template <int L>
 __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
     const float* __restrict__ P, const float* __restrict__ Qall, const float* __restrict__ alphas,
     const float* __restrict__ dalp, const float* __restrict__ dalphas_in, const float* __restrict__ w_full,
     int B, int t, int T, const int* __restrict__ dec_len, float inv_temp, float* __restrict__ dPacc,
     float* __restrict__ dqp, float* __restrict__ dwf_acc, float* __restrict__ dbf_acc) {
-  __shared__ float de_s[kL];
+  __shared__ float de_s[L];
   __shared__ float red_s[4];
   __shared__ float dbf_s[8];
   __shared__ __align__(16) float acc_s[8][2][kA];
@@ -527,30 +537,31 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
   // BPTT runs t = T-1 .. 0; row b joins at its own last step, where its accumulators are initialised
   const bool first_step = (t == dec_len[b] - 1);
   float al = 0.f, da = 0.f;
-  if (tid < kL) {
-    al = alphas[bt * kL + tid];
+  if (tid < L) {
+    al = alphas[bt * L + tid];
 #pragma unroll
-    for (int c = 0; c < kNCH; ++c) da += dalp[((long long)c * B + b) * kL + tid];
-    if (dalphas_in) da += dalphas_in[bt * kL + tid];
+    for (int c = 0; c < kNCH; ++c) da += dalp[((long long)c * B + b) * L + tid];
+    if (dalphas_in) da += dalphas_in[bt * L + tid];
   }
   const float part = wave_sum(al * da);
   if (lane == 0) red_s[w] = part;
   __syncthreads();
   const float dot = red_s[0] + red_s[1] + red_s[2] + red_s[3];
-  if (tid < kL) de_s[tid] = al * (da - dot) * inv_temp;
+  if (tid < L) de_s[tid] = al * (da - dot) * inv_temp;
   __syncthreads();
   const int l32 = lane & 31, sub = lane >> 5, hw = w * 2 + sub;      // 8 half-waves
   const float4 q4 = *reinterpret_cast<const float4*>(Qall + bt * kA + l32 * 4);
   const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
   float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), dw4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbf = 0.f;
-  const int l_lo = lch * (kL / kLCH), l_hi = l_lo + kL / kLCH;
-  constexpr int NIT = (kL / kLCH + 7) / 8;          // 49 cells over 8 half-waves -> 7 passes, all loads up front
+  constexpr int SLICE = 49;                          // cells per workgroup (grid.x = L / 49 slices)
+  const int l_lo = lch * SLICE, l_hi = l_lo + SLICE;
+  constexpr int NIT = (SLICE + 7) / 8;          // 49 cells over 8 half-waves -> 7 passes, all loads up front
   float4 p4v[NIT], oldv[NIT];
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int l = min(l_lo + hw + 8 * i, l_hi - 1);
-    const long long o = ((long long)b * kL + l) * kA + l32 * 4;
+    const long long o = ((long long)b * L + l) * kA + l32 * 4;
     p4v[i] = *reinterpret_cast<const float4*>(P + o);                 // clamped cell: branch-free, unused when l >= l_hi
     oldv[i] = *reinterpret_cast<const float4*>(dPacc + o);
     if (first_step) oldv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -559,7 +570,7 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
   for (int i = 0; i < NIT; ++i) {
     const int l = l_lo + hw + 8 * i;
     if (l < l_hi) {
-      const long long o = ((long long)b * kL + l) * kA + l32 * 4;
+      const long long o = ((long long)b * L + l) * kA + l32 * 4;
       const float4 p4 = p4v[i];
       const float de = de_s[l];
       const float r0 = p4.x + q4.x, r1 = p4.y + q4.y, r2 = p4.z + q4.z, r3 = p4.w + q4.w;
@@ -602,25 +613,25 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
 // dF[b,l,d] = sum_t alpha[b,t,l] * dctx[b,t,d] + dmean[b,d] / L     (the W_z^T dP term is added by an
 // accumulating MFMA GEMM afterwards).  grid (kNCH, B); dctx of this thread's channel in registers.
 // ------------------------------------------------------------------------------------------
-template <int TMAXR>
+template <int L, int TMAXR>
 __global__ void __launch_bounds__(256) dF_init_kernel(const float* __restrict__ alphas, const float* __restrict__ dctx_all,
                                                        const float* __restrict__ dmean, int T, int Tb_unused,
                                                        const int* __restrict__ dec_len, float* __restrict__ dF) {
-  extern __shared__ __align__(16) float al_s[];   // [kL][TMAXR]
+  extern __shared__ __align__(16) float al_s[];   // [L][TMAXR]
   const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int d = chunk * 256 + tid;
   const int Tb = min(dec_len[b], T);
-  for (int i = tid; i < kL * TMAXR; i += 256) {
+  for (int i = tid; i < L * TMAXR; i += 256) {
     const int l = i / TMAXR, tt = i - l * TMAXR;
-    al_s[i] = (tt < Tb) ? alphas[((long long)b * T + tt) * kL + l] : 0.f;
+    al_s[i] = (tt < Tb) ? alphas[((long long)b * T + tt) * L + l] : 0.f;
   }
   float dc[TMAXR];
 #pragma unroll
   for (int tt = 0; tt < TMAXR; ++tt) dc[tt] = (tt < Tb) ? dctx_all[((long long)b * T + tt) * kD + d] : 0.f;
-  const float dm = dmean[(long long)b * kD + d] / (float)kL;
+  const float dm = dmean[(long long)b * kD + d] / (float)L;
   __syncthreads();
-  float* o = dF + (long long)b * kL * kD + d;
-  for (int l = 0; l < kL; ++l) {
+  float* o = dF + (long long)b * L * kD + d;
+  for (int l = 0; l < L; ++l) {
     float s = dm;
 #pragma unroll
     for (int t4 = 0; t4 < TMAXR; t4 += 4) {
@@ -716,6 +727,42 @@ static int gemm(int M, int N, int K, GemmOperand A, GemmOperand B, GemmEpilogue 
 }
 
 // raw split-K partial slabs [splitk][M][N] (no reduce launch; the consumer kernel sums the slabs)
+// ------------------------------------------------------------------------------------------
+// Compact (49-cell) mode.  At 224x224 both encoders end in a 7x7 map that AdaptiveAvgPool2d(14) replicates 2x2 exactly
+// (quirk Q3), so the 196 annotation cells hold 49 distinct vectors.  Equal scores within a group make
+// softmax_196 = softmax_49 / 4 and ctx = sum_g beta_g F_g: the decoder runs on the 49 distinct cells (every pass over
+// F and P is 4x smaller) and only the returned alphas are expanded / the incoming alpha gradient is folded.
+// Group g = (i, j) of the 7x7 map <-> cells (2i + di) * 14 + (2j + dj).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) expand_alphas_kernel(const float* __restrict__ ac, float* __restrict__ a,
+                                                             long long n) {       // n = B*T*196
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long bt = i / kL;
+  const int cell = (int)(i - bt * kL);
+  const int g = (cell / 28) * 7 + (cell % 14) / 2;
+  a[i] = 0.25f * ac[bt * kLc + g];
+}
+__global__ void __launch_bounds__(256) fold_dalphas_kernel(const float* __restrict__ da, float* __restrict__ dc,
+                                                            long long n) {        // n = B*T*49
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long bt = i / kLc;
+  const int g = (int)(i - bt * kLc);
+  const float* r = da + bt * kL + (g / 7) * 28 + (g % 7) * 2;
+  dc[i] = 0.25f * ((r[0] + r[1]) + (r[14] + r[15]));
+}
+
+// runs STMT with a compile-time cell count L_ (196 = reference layout, 49 = compact)
+#define DIC_CELLS_SWITCH(CELLS, STMT)   \
+  if ((CELLS) == kL) {                  \
+    constexpr int L_ = kL;              \
+    STMT                                \
+  } else {                              \
+    constexpr int L_ = kLc;             \
+    STMT                                \
+  }
+
 static int gemm_slabs(int M, int N, int K, GemmOperand A, GemmOperand B, float* slabs, int splitk, hipStream_t st) {
   GemmParams p{};
   p.M = M; p.N = N; p.K = K; p.A = A; p.B = B; p.ep = ep_store(slabs, N); p.splitk = splitk; p.ws = slabs;
@@ -740,13 +787,17 @@ size_t dic_decoder_workspace_bytes(int B, int Tmax, int V, int n_packed) {
   return decoder_carve(nullptr, 0, B, Tmax, V, n_packed, &ov).bytes;
 }
 
-int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth,
-                    const int64_t* captions, int cap_stride, const int* dec_lengths, int B, const float* drop_mult,
-                    int mode, const float* gumbel_u, float temp, float* logits_packed, float* alphas, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth,
+                            const int64_t* captions, int cap_stride, const int* dec_lengths, int B,
+                            const float* drop_mult, int mode, const float* gumbel_u, float temp, float* logits_packed,
+                            float* alphas_out, void* workspace, size_t workspace_bytes, void* stream, int cells) {
   hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(cells == kL || cells == kLc, "decoder_fwd: cells must be 196 or 49");
+  DIC_REQUIRE(cells == kL || mode == 0, "decoder_fwd: the compact 49-cell layout needs soft attention (per-cell Gumbel "
+                                        "noise breaks the 2x2 symmetry)");
+  float* const alphas_out_ = alphas_out;
   DIC_TRY(check_common(w, V, B, workspace));
-  DIC_REQUIRE(feat_rgb && captions && logits_packed && alphas, "decoder_fwd: null pointer");
+  DIC_REQUIRE(feat_rgb && captions && logits_packed && alphas_out, "decoder_fwd: null pointer");
   DIC_REQUIRE(mode >= 0 && mode <= 2, "decoder_fwd: mode must be 0 (soft), 1 (gumbel-softmax) or 2 (gumbel-max)");
   DIC_REQUIRE(mode == 0 || gumbel_u != nullptr, "decoder_fwd: hard attention needs the uniform draws");
   StepPlan pl;
@@ -758,7 +809,8 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
 
   int* d_len = ws.dlen;                                  // device copy of dec_lengths
   DIC_CHECK_HIP(hipMemcpyAsync(d_len, dec_lengths, sizeof(int) * B, hipMemcpyHostToDevice, st));
-  DIC_CHECK_HIP(hipMemsetAsync(alphas, 0, sizeof(float) * (size_t)B * T * kL, st));
+  float* alphas = (cells == kL) ? alphas_out_ : ws.alpha_c;      // [B,T,cells]: what the step kernels write
+  DIC_CHECK_HIP(hipMemsetAsync(alphas, 0, sizeof(float) * (size_t)B * T * cells, st));
   DIC_CHECK_HIP(hipMemsetAsync(ws.Xall, 0, sizeof(float) * (size_t)B * T * kXK, st));
 
   // weight prep: fused LSTM weight, transposed small matrices for coalesced mat-vecs
@@ -767,10 +819,11 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
   DIC_TRY(launch_transpose(w->dec_att_w, ws.WhT, kA, kH, st));
   DIC_TRY(launch_transpose(w->fbeta_w, ws.WbT, kD, kH, st));
   // F = F_rgb + F_depth, mean over cells
-  hipLaunchKernelGGL(fuse_mean_kernel, dim3(kNCH, B), dim3(256), 0, st, feat_rgb, feat_depth, ws.F, ws.mean);
+  DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(fuse_mean_kernel<L_>, dim3(kNCH, B), dim3(256), 0, st, feat_rgb, feat_depth,
+                                             ws.F, ws.mean);)
   DIC_LAUNCH_CHECK();
   // P = Wz F + bz  (hoisted: time-invariant, quirk Q4)
-  DIC_TRY(gemm(B * kL, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st));
+  DIC_TRY(gemm(B * cells, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st));
   // [h0 | c0] = init_linear(mean)  -> slot 0 of Hall / Call
   {
     GemmEpilogue ep = ep_store(ws.Hall, (long long)(T + 1) * kH, w->init_b);
@@ -783,9 +836,9 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
 
   for (int t = 0; t < T; ++t) {
     const int nb = pl.bs[t];
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
-                       w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, temp, alphas,
-                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
+    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_fwd_kernel<L_>, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.P, ws.Hall,
+                                               ws.WhT, w->dec_att_b, w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t,
+                                               T, mode, gumbel_u, B, temp, alphas, ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);)
     DIC_LAUNCH_CHECK();
     DIC_TRY(gemm_slabs(nb, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
@@ -793,19 +846,44 @@ int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, 
                        pl.off[t], ws.Hall, ws.Call, ws.Gact, ws.Hdrop);
     DIC_LAUNCH_CHECK();
   }
+  if (cells != kL) {      // returned attention weights in the reference's 196-cell layout: alpha_cell = beta_group / 4
+    const long long n = (long long)B * T * kL;
+    hipLaunchKernelGGL(expand_alphas_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws.alpha_c, alphas_out_, n);
+    DIC_LAUNCH_CHECK();
+  }
   // logits (time-major packed rows) = dropout(h) W_o^T + b_o    (depth_models.py:197,204)
   DIC_TRY(gemm(N, V, kH, op_rowk(ws.Hdrop, kH), op_rowk(w->out_w, kH), ep_store(logits_packed, V, w->out_b), st));
   return DIC_OK;
 }
 
-int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions, int cap_stride,
-                    const int* dec_lengths, int B, const float* drop_mult, int mode, float temp,
-                    const float* dlogits_packed, const float* dalphas, const float* alphas,
-                    const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
-                    void* stream) {
+extern "C" int dic_decoder_fwd(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth,
+                               const int64_t* captions, int cap_stride, const int* dec_lengths, int B,
+                               const float* drop_mult, int mode, const float* gumbel_u, float temp, float* logits_packed,
+                               float* alphas, void* workspace, size_t workspace_bytes, void* stream) {
+  return decoder_fwd_impl(w, V, feat_rgb, feat_depth, captions, cap_stride, dec_lengths, B, drop_mult, mode, gumbel_u, temp,
+                          logits_packed, alphas, workspace, workspace_bytes, stream, kL);
+}
+
+extern "C" int dic_decoder_fwd_cells(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth,
+                                     int cells, const int64_t* captions, int cap_stride, const int* dec_lengths, int B,
+                                     const float* drop_mult, float* logits_packed, float* alphas, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return decoder_fwd_impl(w, V, feat_rgb, feat_depth, captions, cap_stride, dec_lengths, B, drop_mult, 0, nullptr, 1.0f,
+                          logits_packed, alphas, workspace, workspace_bytes, stream, cells);
+}
+
+static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* captions, int cap_stride,
+                            const int* dec_lengths, int B, const float* drop_mult, int mode, float temp,
+                            const float* dlogits_packed, const float* dalphas_in, const float* alphas_in,
+                            const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
+                            void* stream, int cells) {
   hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(cells == kL || (cells == kLc && mode == 0), "decoder_bwd: cells must be 196, or 49 with soft attention");
+  const float* alphas = alphas_in;
+  const float* dalphas = dalphas_in;
+  const int nlch = cells / 49;                 // score-backward slices of 49 cells
   DIC_TRY(check_common(w, V, B, workspace));
-  DIC_REQUIRE(g && dlogits_packed && alphas && captions, "decoder_bwd: null pointer");
+  DIC_REQUIRE(g && dlogits_packed && alphas_in && captions, "decoder_bwd: null pointer");
   DIC_REQUIRE(mode == 0 || mode == 1, "decoder_bwd: only soft (0) and gumbel-softmax (1) attention are differentiable");
   StepPlan pl;
   DIC_TRY(make_plan(dec_lengths, B, &pl));
@@ -824,6 +902,15 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
   DIC_CHECK_HIP(hipMemsetAsync(ws.dq, 0, sizeof(float) * BT * kA, st));
   DIC_CHECK_HIP(hipMemsetAsync(g->embed, 0, sizeof(float) * (size_t)V * kE, st));
   float* cs = ws.colsum_ws;
+  if (cells != kL) {      // compact layout: beta = group softmax saved by the forward; fold the 196-cell alpha gradient
+    alphas = ws.alpha_c;
+    if (dalphas_in) {
+      const long long n = (long long)B * T * kLc;
+      hipLaunchKernelGGL(fold_dalphas_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dalphas_in, ws.dalpha_c, n);
+      DIC_LAUNCH_CHECK();
+      dalphas = ws.dalpha_c;
+    }
+  }
 
   // vocabulary projection backward (batched over all steps)
   DIC_TRY(gemm(N, kH, V, op_rowk(dlogits_packed, V), op_colk(w->out_w, kH), ep_store(ws.dHd, kH), st, 8, ws.gemm_ws));
@@ -835,23 +922,25 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
     const int nb = pl.bs[t];
     const int have_next = (t + 1 < T);
     const int nb_next = have_next ? pl.bs[t + 1] : 0;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nb), dim3(kH), 0, st, t, T, B, nb_next, have_next, 0, ws.dHd, pl.off[t],
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nb), dim3(kH), 0, st, t, T, B, nb_next, have_next, 0, nlch, ws.dHd, pl.off[t],
                        drop_mult, ws.slab_dx, kS_DX, nb_next, ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call,
                        ws.carry_dc, ws.dG, ws.dq, ws.dinit);
     DIC_LAUNCH_CHECK();
     // dX = dG_t * Wcat  (K = 4H)
     DIC_TRY(gemm_slabs(nb, kXK, kG, op_rowk(ws.dG + (long long)t * kG, (long long)T * kG), op_rowk(ws.WcatT, kG),
                        ws.slab_dx, kS_DX, st));
-    hipLaunchKernelGGL(attn_bwd_a_kernel, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.slab_dx, kS_DX, nb, B, t, T,
-                       ws.ctx, ws.gate, w->fbeta_w, (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre,
-                       ws.dalp, ws.pbeta, g->embed);
+    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_a_kernel<L_>, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.slab_dx,
+                                               kS_DX, nb, B, t, T, ws.ctx, ws.gate, w->fbeta_w,
+                                               (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre, ws.dalp,
+                                               ws.pbeta, g->embed);)
     DIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_b_kernel, dim3(kLCH, nb), dim3(256), 0, st, ws.P, ws.Qall, alphas, ws.dalp, dalphas,
-                       w->full_att_w, B, t, T, ws.dlen, inv_temp, ws.dPacc, ws.dqp, ws.dwf_acc, ws.dbf_acc);
+    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_b_kernel<L_>, dim3(nlch, nb), dim3(256), 0, st, ws.P, ws.Qall, alphas,
+                                               ws.dalp, dalphas, w->full_att_w, B, t, T, ws.dlen, inv_temp, ws.dPacc,
+                                               ws.dqp, ws.dwf_acc, ws.dbf_acc);)
     DIC_LAUNCH_CHECK();
   }
   // gradient of (h0 | c0) and the dq of step 0
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(kH), 0, st, -1, T, B, pl.bs[0], 1, 1, ws.dHd, 0, drop_mult,
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(kH), 0, st, -1, T, B, pl.bs[0], 1, 1, nlch, ws.dHd, 0, drop_mult,
                      ws.slab_dx, kS_DX, pl.bs[0], ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call, ws.carry_dc, ws.dG,
                      ws.dq, ws.dinit);
   DIC_LAUNCH_CHECK();
@@ -872,11 +961,11 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
   DIC_TRY(gemm(kA, kH, (int)BT, op_colk(ws.dq, kA), op_colk(Hprev, kXK), ep_store(g->dec_att_w, kH), st, 8, ws.gemm_ws));
   DIC_TRY(colsum(ws.dq, kA, (int)BT, kA, g->dec_att_b, cs, st));
   // full_att
-  DIC_TRY(colsum(ws.dwf_acc, kA, kLCH * B, kA, g->full_att_w, cs, st));
-  DIC_TRY(colsum(ws.dbf_acc, 1, kLCH * B, 1, g->full_att_b, cs, st));
+  DIC_TRY(colsum(ws.dwf_acc, kA, nlch * B, kA, g->full_att_w, cs, st));
+  DIC_TRY(colsum(ws.dbf_acc, 1, nlch * B, 1, g->full_att_b, cs, st));
   // encoder_att: dW_z = dP^T F, db_z = colsum(dP)
-  DIC_TRY(gemm(kA, kD, B * kL, op_colk(ws.dPacc, kA), op_colk(ws.F, kD), ep_store(g->enc_att_w, kD), st, 8, ws.gemm_ws));
-  DIC_TRY(colsum(ws.dPacc, kA, B * kL, kA, g->enc_att_b, cs, st));
+  DIC_TRY(gemm(kA, kD, B * cells, op_colk(ws.dPacc, kA), op_colk(ws.F, kD), ep_store(g->enc_att_w, kD), st, 8, ws.gemm_ws));
+  DIC_TRY(colsum(ws.dPacc, kA, B * cells, kA, g->enc_att_b, cs, st));
   // init_linear
   DIC_TRY(gemm(2 * kH, kD, B, op_colk(ws.dinit, 2 * kH), op_colk(ws.mean, kD), ep_store(g->init_w, kD), st));
   DIC_TRY(colsum(ws.dinit, 2 * kH, B, 2 * kH, g->init_b, cs, st));
@@ -885,20 +974,38 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
   // ---- gradient w.r.t. the fused feature map (same for F_rgb and F_depth: F = F_rgb + F_depth) ----
   if (d_features) {
     if (T <= 32) {
-      hipLaunchKernelGGL((dF_init_kernel<32>), dim3(kNCH, B), dim3(256), kL * 32 * sizeof(float), st, alphas, ws.dctx,
-                         ws.dmean, T, 0, d_len, d_features);
+      DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL((dF_init_kernel<L_, 32>), dim3(kNCH, B), dim3(256), L_ * 32 * sizeof(float),
+                                                 st, alphas, ws.dctx, ws.dmean, T, 0, d_len, d_features);)
     } else {
-      hipLaunchKernelGGL((dF_init_kernel<64>), dim3(kNCH, B), dim3(256), kL * 64 * sizeof(float), st, alphas, ws.dctx,
-                         ws.dmean, T, 0, d_len, d_features);
+      DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL((dF_init_kernel<L_, 64>), dim3(kNCH, B), dim3(256), L_ * 64 * sizeof(float),
+                                                 st, alphas, ws.dctx, ws.dmean, T, 0, d_len, d_features);)
     }
     DIC_LAUNCH_CHECK();
     GemmEpilogue ep = ep_store(d_features, kD);
     ep.accumulate = 1;
     // dF += dP W_z: W_z^T ([D][A], K-contiguous rows) keeps this 6.6-GFLOP product on the LDS-DMA kernel
     DIC_TRY(launch_transpose(w->enc_att_w, ws.WzT, kA, kD, st));
-    DIC_TRY(gemm(B * kL, kD, kA, op_rowk(ws.dPacc, kA), op_rowk(ws.WzT, kA), ep, st));
+    DIC_TRY(gemm(B * cells, kD, kA, op_rowk(ws.dPacc, kA), op_rowk(ws.WzT, kA), ep, st));
   }
   return DIC_OK;
+}
+
+extern "C" int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions, int cap_stride,
+                               const int* dec_lengths, int B, const float* drop_mult, int mode, float temp,
+                               const float* dlogits_packed, const float* dalphas, const float* alphas,
+                               const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return decoder_bwd_impl(w, V, captions, cap_stride, dec_lengths, B, drop_mult, mode, temp, dlogits_packed, dalphas, alphas,
+                          g, d_features, workspace, workspace_bytes, stream, kL);
+}
+
+extern "C" int dic_decoder_bwd_cells(const dic_decoder_weights* w, int V, int cells, const int64_t* captions,
+                                     int cap_stride, const int* dec_lengths, int B, const float* drop_mult,
+                                     const float* dlogits_packed, const float* dalphas, const float* alphas,
+                                     const dic_decoder_grads* g, float* d_features, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return decoder_bwd_impl(w, V, captions, cap_stride, dec_lengths, B, drop_mult, 0, 1.0f, dlogits_packed, dalphas, alphas, g,
+                          d_features, workspace, workspace_bytes, stream, cells);
 }
 
 size_t dic_decoder_greedy_workspace_bytes(int B, int max_length, int V) {
@@ -923,7 +1030,7 @@ int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rg
   hipLaunchKernelGGL(pack_lstm_kernel, dim3(kG), dim3(256), 0, st, w->w_ih, w->w_hh, w->b_ih, w->b_hh, ws.Wcat, ws.bcat);
   DIC_TRY(launch_transpose(w->dec_att_w, ws.WhT, kA, kH, st));
   DIC_TRY(launch_transpose(w->fbeta_w, ws.WbT, kD, kH, st));
-  hipLaunchKernelGGL(fuse_mean_kernel, dim3(kNCH, B), dim3(256), 0, st, feat_rgb, feat_depth, ws.F, ws.mean);
+  hipLaunchKernelGGL(fuse_mean_kernel<kL>, dim3(kNCH, B), dim3(256), 0, st, feat_rgb, feat_depth, ws.F, ws.mean);
   DIC_LAUNCH_CHECK();
   DIC_TRY(gemm(B * kL, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st));
   {
@@ -935,7 +1042,7 @@ int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rg
   DIC_LAUNCH_CHECK();
   for (int t = 0; t < T; ++t) {
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(kE), 0, st, w->embed, ws.ids, t, T, V, ws.Xall);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
+    hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, B), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
                        w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, 1.0f, alphas,
                        ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
     DIC_LAUNCH_CHECK();
@@ -978,7 +1085,7 @@ int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const floa
                                  hipMemcpyDeviceToDevice, st));
   DIC_TRY(launch_transpose(dec_att_w, WhT, kA, kH, st));
   DIC_TRY(gemm(B * kL, kA, kD, op_rowk(feats, kD), op_rowk(enc_att_w, kD), ep_store(P, kA, enc_att_b), st));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(kNCH, B), dim3(512), 0, st, feats, (const float*)P, (const float*)H2,
+  hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, B), dim3(512), 0, st, feats, (const float*)P, (const float*)H2,
                      (const float*)WhT, dec_att_b, full_att_w, full_att_b, (const float*)nullptr,
                      (const float*)nullptr, 0, 1, mode, gumbel_u, B, temp, alpha, (float*)nullptr, ctx,
                      (float*)nullptr, (float*)nullptr, 0);

@@ -93,6 +93,21 @@ int dic_decoder_bwd(const dic_decoder_weights* w, int V, const int64_t* captions
                     const dic_decoder_grads* g, float* d_features, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Compact 49-cell layout (soft attention only).  At 224x224 both encoders end in a 7x7 map that AdaptiveAvgPool2d(14)
+ * replicates 2x2 exactly (base_caption_models.py:27,41; depth_models.py:47,54), so the 196 annotation cells hold 49
+ * distinct vectors, softmax_196 = softmax_49 / 4 and ctx = sum_g beta_g F_g.  With cells = 49 feat_rgb / feat_depth /
+ * d_features are [B,49,2048] (the 7x7 maps, row-major), every pass over the feature map is 4x smaller, and the results
+ * (logits, alphas [B,T,196] in the reference's cell order, all parameter gradients) equal the 196-cell evaluation up to
+ * fp32 rounding; d_features is then the gradient w.r.t. the 7x7 map (= the sum over each 2x2 group).
+ * cells = 196 is identical to dic_decoder_fwd / dic_decoder_bwd with mode 0.  Same workspace as those. */
+int dic_decoder_fwd_cells(const dic_decoder_weights* w, int V, const float* feat_rgb, const float* feat_depth, int cells,
+                          const int64_t* captions, int cap_stride, const int* dec_lengths, int B, const float* drop_mult,
+                          float* logits_packed, float* alphas, void* workspace, size_t workspace_bytes, void* stream);
+int dic_decoder_bwd_cells(const dic_decoder_weights* w, int V, int cells, const int64_t* captions, int cap_stride,
+                          const int* dec_lengths, int B, const float* drop_mult, const float* dlogits_packed,
+                          const float* dalphas, const float* alphas, const dic_decoder_grads* g, float* d_features,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* greedy decoding: batch_sample / sample (depth_models.py:216-305 soft, 698-789 hard with Gumbel-max).
  *   Starts from id_start (<start>), max_length steps, dropout off, token = argmax(linear(h)); the previous
  *   token stays on the device (the reference copies it to the host every step, :298-299).
