@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 L_CELLS, D_ENC, D_ATT, D_EMB, D_HID = 196, 2048, 128, 128, 128
+L_COMPACT = 49          # distinct annotation cells when the 14x14 grid is a 2x2 replication of a 7x7 map (Q3)
 
 # state_dict key  ->  field of dic_decoder_weights / dic_decoder_grads (include/dic.h)
 DECODER_FIELDS = (
@@ -71,6 +72,7 @@ class DecoderTape:
     temp: float
     alphas: torch.Tensor
     weights: Dict[str, torch.Tensor]
+    cells: int = 196
 
 
 def batch_sizes_of(dec_len: Sequence[int]) -> List[int]:
@@ -81,11 +83,18 @@ def decoder_forward(weights: Dict[str, torch.Tensor], feat_rgb: torch.Tensor, fe
                     captions: torch.Tensor, lengths: Sequence[int], drop_mult: Optional[torch.Tensor] = None,
                     mode: int = 0, gumbel_u: Optional[torch.Tensor] = None, temp: float = 1.0,
                     workspace: Optional[torch.Tensor] = None):
-    """dic_decoder_fwd. Returns (logits_packed [N,V], alphas [B,Tmax,196], tape)."""
+    """dic_decoder_fwd. Returns (logits_packed [N,V], alphas [B,Tmax,196], tape).
+    Features of shape [B,49,2048] (the encoders' 7x7 maps before the 2x2 replication to 14x14) select the compact
+    layout (dic_decoder_fwd_cells, soft attention only): same logits / alphas / gradients, 4x less feature traffic."""
     lib = _lib.load()
     B = feat_rgb.shape[0]
-    if tuple(feat_rgb.shape[1:]) != (L_CELLS, D_ENC):
-        raise _lib.DicError(f"features must be [B,{L_CELLS},{D_ENC}], got {tuple(feat_rgb.shape)}")
+    cells = int(feat_rgb.shape[1])
+    if cells not in (L_CELLS, L_COMPACT) or feat_rgb.shape[2] != D_ENC:
+        raise _lib.DicError(f"features must be [B,{L_CELLS},{D_ENC}] or [B,{L_COMPACT},{D_ENC}], got {tuple(feat_rgb.shape)}")
+    if cells == L_COMPACT and mode != 0:
+        raise _lib.DicError("the compact 49-cell layout supports soft attention only")
+    if feat_depth is not None and tuple(feat_depth.shape) != tuple(feat_rgb.shape):
+        raise _lib.DicError("depth features must have the shape of the RGB features")
     dec_len = [int(l) - 1 for l in lengths]
     tmax = max(dec_len)
     bsz = batch_sizes_of(dec_len)
@@ -106,12 +115,18 @@ def decoder_forward(weights: Dict[str, torch.Tensor], feat_rgb: torch.Tensor, fe
     alphas = torch.empty((B, tmax, L_CELLS), dtype=torch.float32, device=dev)
     dm = _dev_f32(drop_mult, "drop_mult") if drop_mult is not None else None
     gu = _dev_f32(gumbel_u, "gumbel_u") if gumbel_u is not None else None
-    rc = lib.dic_decoder_fwd(C.byref(wp), vocab, ptr(f_rgb), ptr(f_dep), ptr(caps), caps.stride(0),
-                             _i32_host(dec_len), B, ptr(dm), mode, ptr(gu), C.c_float(temp), ptr(logits), ptr(alphas),
-                             ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
-    check(rc, "dic_decoder_fwd")
+    if cells == L_CELLS:
+        rc = lib.dic_decoder_fwd(C.byref(wp), vocab, ptr(f_rgb), ptr(f_dep), ptr(caps), caps.stride(0),
+                                 _i32_host(dec_len), B, ptr(dm), mode, ptr(gu), C.c_float(temp), ptr(logits), ptr(alphas),
+                                 ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+        check(rc, "dic_decoder_fwd")
+    else:
+        rc = lib.dic_decoder_fwd_cells(C.byref(wp), vocab, ptr(f_rgb), ptr(f_dep), cells, ptr(caps), caps.stride(0),
+                                       _i32_host(dec_len), B, ptr(dm), ptr(logits), ptr(alphas), ptr(workspace),
+                                       C.c_size_t(workspace.numel()), stream_ptr())
+        check(rc, "dic_decoder_fwd_cells")
     tape = DecoderTape(workspace, dec_len, bsz, n_packed, tmax, vocab, caps, dm, mode, float(temp), alphas,
-                       {k: t for (k, _), t in zip(DECODER_FIELDS, keep)})
+                       {k: t for (k, _), t in zip(DECODER_FIELDS, keep)}, cells)
     return logits, alphas, tape
 
 
@@ -125,14 +140,21 @@ def decoder_backward(tape: DecoderTape, dlogits: torch.Tensor, dalphas: Optional
         grads = {k: torch.empty_like(t) for k, t in tape.weights.items()}
     gp, keep_g = decoder_ptrs(grads)
     wp, keep_w = decoder_ptrs(tape.weights)
-    dfeat = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=dev) if want_dfeatures else None
+    dfeat = torch.empty((B, tape.cells, D_ENC), dtype=torch.float32, device=dev) if want_dfeatures else None
     dl = _dev_f32(dlogits, "dlogits")
     da = _dev_f32(dalphas, "dalphas") if dalphas is not None else None
-    rc = lib.dic_decoder_bwd(C.byref(wp), tape.vocab, ptr(tape.captions), tape.captions.stride(0),
-                             _i32_host(tape.dec_len), B, ptr(tape.drop_mult), tape.mode, C.c_float(tape.temp), ptr(dl),
-                             ptr(da), ptr(tape.alphas), C.byref(gp), ptr(dfeat), ptr(tape.workspace),
-                             C.c_size_t(tape.workspace.numel()), stream_ptr())
-    check(rc, "dic_decoder_bwd")
+    if tape.cells == L_CELLS:
+        rc = lib.dic_decoder_bwd(C.byref(wp), tape.vocab, ptr(tape.captions), tape.captions.stride(0),
+                                 _i32_host(tape.dec_len), B, ptr(tape.drop_mult), tape.mode, C.c_float(tape.temp), ptr(dl),
+                                 ptr(da), ptr(tape.alphas), C.byref(gp), ptr(dfeat), ptr(tape.workspace),
+                                 C.c_size_t(tape.workspace.numel()), stream_ptr())
+        check(rc, "dic_decoder_bwd")
+    else:       # d_features is then the gradient w.r.t. the 7x7 maps
+        rc = lib.dic_decoder_bwd_cells(C.byref(wp), tape.vocab, tape.cells, ptr(tape.captions), tape.captions.stride(0),
+                                       _i32_host(tape.dec_len), B, ptr(tape.drop_mult), ptr(dl), ptr(da), ptr(tape.alphas),
+                                       C.byref(gp), ptr(dfeat), ptr(tape.workspace), C.c_size_t(tape.workspace.numel()),
+                                       stream_ptr())
+        check(rc, "dic_decoder_bwd_cells")
     return grads, dfeat
 
 

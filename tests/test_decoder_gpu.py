@@ -158,3 +158,48 @@ def test_adamw_and_dropout_kernels(lib):
     assert torch.equal(mask, mask2)                                        # counter-based: reproducible
     mask3 = native.dropout_mask((64, 20, 128), 0.5, seed=123, offset=1 << 20, device=DEV).cpu()
     assert not torch.equal(mask, mask3)
+
+
+def _replicate_2x2(f7):
+    """[B,49,D] (7x7 row-major) -> [B,196,D] in the 14x14 cell order of AdaptiveAvgPool2d(14) on a 7x7 map (Q3)."""
+    B, _, D = f7.shape
+    g = f7.view(B, 7, 1, 7, 1, D).expand(B, 7, 2, 7, 2, D)
+    return g.reshape(B, 196, D).contiguous()
+
+
+@pytest.mark.parametrize("lengths", [[9, 7, 7, 4, 3], [6, 6, 6, 6]])
+def test_compact_49_cell_layout_equals_196(lib, lengths):
+    """The compact layout (dic_decoder_fwd_cells / _bwd_cells, cells = 49) must reproduce the 196-cell evaluation on
+    2x2-replicated feature maps: logits, alphas (196-cell order), every parameter gradient, and d_features equal to the
+    sum of the 196-cell gradient over each 2x2 group (what AdaptiveAvgPool2d's backward would produce)."""
+    vocab = 60
+    B = len(lengths)
+    w = {k: v.to(DEV) for k, v in syn.decoder_weights(vocab, seed=91).items()}
+    g = torch.Generator().manual_seed(92)
+    f7r = torch.randn(B, 49, 2048, generator=g).mul_(0.7).to(DEV)
+    f7d = torch.randn(B, 49, 2048, generator=g).mul_(0.3).to(DEV)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=93)
+    caps = caps.to(DEV)
+    T = max(lens) - 1
+    drop = syn.dropout_multiplier(B, T, 0.5, seed=94).to(DEV)
+    out = {}
+    for name, fr, fd in (("full", _replicate_2x2(f7r), _replicate_2x2(f7d)), ("compact", f7r, f7d)):
+        logits, alphas, tape = native.decoder_forward(w, fr, fd, caps, lens, drop_mult=drop)
+        dl = torch.cos(torch.arange(logits.numel(), device=DEV, dtype=torch.float32).view_as(logits) * 0.37) * 1e-2
+        da = torch.sin(torch.arange(alphas.numel(), device=DEV, dtype=torch.float32).view_as(alphas) * 0.11) * 1e-2
+        grads, dfeat = native.decoder_backward(tape, dl.clone(), da)
+        out[name] = (logits, alphas, grads, dfeat)
+    lf, af, gf, df = out["full"]
+    lc, ac, gc, dc = out["compact"]
+    assert af.shape == ac.shape == (B, T, 196) and dc.shape == (B, 49, 2048)
+
+    def close(name, a, b, tol, atol=0.0):
+        err = float((a - b).abs().max())
+        scale = float(b.abs().max()) + 1e-12
+        assert err <= tol * scale + atol, f"{name}: {err:.3e} vs scale {scale:.3e}"
+    close("logits", lc, lf, 2e-5)
+    close("alphas", ac, af, 2e-5)
+    for k in gf:
+        close("grad " + k, gc[k], gf[k], 2e-4, atol=1e-7)
+    df_groups = df.view(B, 7, 2, 7, 2, 2048).sum(dim=(2, 4)).reshape(B, 49, 2048)
+    close("d_features", dc, df_groups, 2e-4)
