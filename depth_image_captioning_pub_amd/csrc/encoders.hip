@@ -218,7 +218,7 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
 // ResNet forward with the bf16x3 convolution: every activation that feeds a convolution is kept as three bf16 planes
 // (written by the BatchNorm-apply kernels), block outputs additionally in fp32 for the residual connection.
 static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, const float* imgs_nchw, int B, int train_bn,
-                          float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st) {
+                          float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st, int pool_out) {
   size_t ci = 0;
   float *X = ws.act[0], *A = ws.act[1], *Bf = ws.act[2], *Cf = ws.act[3];
   unsigned short* const* Xp = ws.planes[0];
@@ -254,11 +254,13 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       // block also writes fp32, for the pooling that follows
       const bool last = (s == 3 && b == blocks[s] - 1);
       const unsigned short* idp[3] = {Xp[0], Xp[1], Xp[2]};
-      DIC_TRY(bn_apply_planes(A, identity, identity ? nullptr : idp, last ? X : nullptr, P1, c3.d.M(), c3.d.CO, ws.bn, 1,
+      // (pool_out == 0: the final map itself is the output, written in place of the fp32 copy)
+      DIC_TRY(bn_apply_planes(A, identity, identity ? nullptr : idp, last ? (pool_out == 0 ? features : X) : nullptr, P1, c3.d.M(), c3.d.CO, ws.bn, 1,
                               st));
       std::swap(Xp, P1);
     }
-  return adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, 14, features, st);
+  if (pool_out == 0) return DIC_OK;       // features already hold the [B, outH*outW, 2048] map
+  return adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, pool_out, features, st);
 }
 
 }  // namespace dic
@@ -278,9 +280,9 @@ size_t dic_depth_encoder_workspace_bytes(int B, int H, int W) {
   return depth_carve(nullptr, 0, depth_geom(B, H, W), &ov).bytes;
 }
 
-int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
-                          int H, int W, int train, float* features, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
+                                  int H, int W, int train, float* features, void* workspace, size_t workspace_bytes,
+                                  void* stream, int pool_out) {
   hipStream_t st = (hipStream_t)stream;
   DIC_REQUIRE(w && s && depth && features && workspace, "depth_encoder_fwd: null pointer");
   DIC_REQUIRE(B > 0 && H >= 43 && W >= 43, "depth_encoder_fwd: input too small (%dx%d)", H, W);
@@ -312,13 +314,27 @@ int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn
   DIC_TRY(conv_fwd(ws.y2p, g.c3, w->conv3_w, w->conv3_b, ws.x3, train ? ws.partial : nullptr, &mt, st));
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, ws.red, st));
   else DIC_TRY(bn_finalize_eval(2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
-  DIC_TRY(adaptive_avgpool(ws.x3, B, g.P2h, g.P2w, 2048, &ws.bn3, 1, 14, features, st));
+  //   pool_out == 0: BN + ReLU only, output = the [B, P2h*P2w, 2048] map (requires a square map)
+  DIC_REQUIRE(pool_out != 0 || g.P2h == g.P2w, "depth_encoder_fwd_map: the feature map must be square");
+  DIC_TRY(adaptive_avgpool(ws.x3, B, g.P2h, g.P2w, 2048, &ws.bn3, 1, pool_out ? pool_out : g.P2h, features, st));
   return DIC_OK;
 }
 
-int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth, const float* d_features, int B, int H,
-                          int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
+int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
+                          int H, int W, int train, float* features, void* workspace, size_t workspace_bytes,
                           void* stream) {
+  return depth_encoder_fwd_impl(w, s, depth, B, H, W, train, features, workspace, workspace_bytes, stream, 14);
+}
+
+int dic_depth_encoder_fwd_map(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
+                              int H, int W, int train, float* feature_map, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  return depth_encoder_fwd_impl(w, s, depth, B, H, W, train, feature_map, workspace, workspace_bytes, stream, 0);
+}
+
+static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const float* depth, const float* d_features, int B, int H,
+                                  int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
+                                  void* stream, int pool_out) {
   hipStream_t st = (hipStream_t)stream;
   DIC_REQUIRE(w && depth && d_features && gr && workspace, "depth_encoder_bwd: null pointer");
   const DepthGeom g = depth_geom(B, H, W);
@@ -326,7 +342,7 @@ int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth
   DepthWs ws = depth_carve(workspace, workspace_bytes, g, &ov);
   DIC_REQUIRE(!ov, "depth_encoder_bwd: workspace too small");
   // layer 3
-  DIC_TRY(adaptive_avgpool_bwd(d_features, B, g.P2h, g.P2w, 2048, 14, ws.dy3, st));
+  DIC_TRY(adaptive_avgpool_bwd(d_features, B, g.P2h, g.P2w, 2048, pool_out ? pool_out : g.P2h, ws.dy3, st));
   DIC_TRY(relu_mask_bwd(ws.dy3, ws.x3, g.M3, 2048, ws.bn3, st));
   DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st));
   DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));   // OHWI == OIHW for 1x1
@@ -355,6 +371,18 @@ int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth
   return DIC_OK;
 }
 
+int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth, const float* d_features, int B, int H,
+                          int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  return depth_encoder_bwd_impl(w, depth, d_features, B, H, W, gr, workspace, workspace_bytes, stream, 14);
+}
+
+int dic_depth_encoder_bwd_map(const dic_depth_encoder_weights* w, const float* depth, const float* d_feature_map, int B,
+                              int H, int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  return depth_encoder_bwd_impl(w, depth, d_feature_map, B, H, W, gr, workspace, workspace_bytes, stream, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 int dic_resnet_num_layers(const int* blocks) {
   int n = 1;
@@ -367,9 +395,9 @@ size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mo
   return rn_carve(nullptr, 0, resnet_plan(B, H, W, blocks), mode, &ov).bytes;
 }
 
-int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
-                   int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
-                   void* stream) {
+static int resnet_fwd_impl(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
+                           int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
+                           void* stream, int pool_out) {
   hipStream_t st = (hipStream_t)stream;
   DIC_REQUIRE(layers && blocks && imgs_nchw && features && workspace, "resnet_fwd: null pointer");
   DIC_REQUIRE(n_layers == dic_resnet_num_layers(blocks), "resnet_fwd: expected %d conv+bn layers, got %d",
@@ -383,7 +411,7 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
   if (mode == 1) {
     for (int i = 1; i < n_layers; ++i)
       DIC_REQUIRE(layers[i].w_hi && layers[i].w_mid && layers[i].w_lo, "resnet_fwd: bf16x3 mode needs split weights");
-    return resnet_fwd_bf3(layers, blocks, imgs_nchw, B, train_bn, features, pl, ws, st);
+    return resnet_fwd_bf3(layers, blocks, imgs_nchw, B, train_bn, features, pl, ws, st, pool_out);
   }
 
   size_t ci = 0;
@@ -415,8 +443,26 @@ int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blo
       std::swap(X, Bf);
     }
   // AdaptiveAvgPool2d(14) + permute(0,2,3,1).flatten(1,2): NHWC already is [B,196,2048]
-  DIC_TRY(adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, 14, features, st));
+  if (pool_out == 0) {
+    DIC_CHECK_HIP(hipMemcpyAsync(features, X, sizeof(float) * (size_t)B * pl.outH * pl.outW * 2048, hipMemcpyDeviceToDevice, st));
+    return DIC_OK;
+  }
+  DIC_TRY(adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, pool_out, features, st));
   return DIC_OK;
+}
+
+int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
+                   int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+  return resnet_fwd_impl(layers, n_layers, blocks, imgs_nchw, B, H, W, train_bn, mode, features, workspace,
+                         workspace_bytes, stream, 14);
+}
+
+int dic_resnet_fwd_map(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
+                       int H, int W, int train_bn, int mode, float* feature_map, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  return resnet_fwd_impl(layers, n_layers, blocks, imgs_nchw, B, H, W, train_bn, mode, feature_map, workspace,
+                         workspace_bytes, stream, 0);
 }
 
 }  // extern "C"

@@ -143,6 +143,10 @@ class CaptionTrainer:
         # (batch shape, output buffer) into a hipGraph and replayed (0.2 ms), so the main stream's work is enqueued
         # right away instead of 9 ms into the step.  DIC_RESNET_GRAPH=0 keeps eager launches.
         self.use_graph = os.environ.get("DIC_RESNET_GRAPH", "1") != "0"
+        # compact 49-cell layout (quirk Q3): at 224x224 both encoders end in a 7x7 map that AdaptiveAvgPool2d(14) only
+        # replicates 2x2, so the soft-attention decoder runs on the 49 distinct cells (same logits / alphas / gradients,
+        # 4x less feature traffic).  DIC_COMPACT_CELLS=0 keeps the reference's 196-cell evaluation everywhere.
+        self.compact_ok = os.environ.get("DIC_COMPACT_CELLS", "1") != "0"
         self.rn_in: Optional[torch.Tensor] = None      # static input of the captured graphs
         self.rn_graphs = {}                            # (shape, buffer index) -> torch.cuda.CUDAGraph
         self.keep_outputs = False      # True: keep logits intact (loss gradient not written in place)
@@ -162,7 +166,7 @@ class CaptionTrainer:
             out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
         return out
 
-    def prefetch_features(self, imgs: torch.Tensor) -> None:
+    def prefetch_features(self, imgs: torch.Tensor, compact: bool = False) -> None:
         """Launch the frozen ResNet-152 forward of an upcoming batch on the side stream.  Legal because the RGB
         encoder takes no gradient and is not touched by the optimiser (depth_train.py:136): its output for batch
         i+1 does not depend on the update of step i; its BatchNorm running statistics are still updated once per
@@ -170,17 +174,20 @@ class CaptionTrainer:
         B = imgs.shape[0]
         i = self.feat_flip
         self.feat_flip ^= 1
-        if self.feat_bufs[i] is None or self.feat_bufs[i].shape[0] != B:
-            self.feat_bufs[i] = torch.empty((B, native.L_CELLS, native.D_ENC), dtype=torch.float32, device=self.device)
+        compact = compact and tuple(imgs.shape[-2:]) == (224, 224)
+        cells = native.L_COMPACT if compact else native.L_CELLS
+        if self.feat_bufs[i] is None or tuple(self.feat_bufs[i].shape[:2]) != (B, cells):
+            self.feat_bufs[i] = torch.empty((B, cells, native.D_ENC), dtype=torch.float32, device=self.device)
+            self.rn_graphs = {k: v for k, v in self.rn_graphs.items() if k[1] != i}      # captured with the old buffer
         ready = torch.cuda.Event()
         ready.record()                                   # inputs + previous readers of this buffer are done
         with torch.cuda.stream(self.side_stream):
             self.side_stream.wait_event(ready)
             feats = self.feat_bufs[i]
             if not self.use_graph:
-                self.resnet.forward(imgs, train_bn=True, out=feats)
+                self.resnet.forward(imgs, train_bn=True, out=feats, compact=compact)
             else:
-                key = (tuple(imgs.shape), i)
+                key = (tuple(imgs.shape), i, compact)
                 if self.rn_in is None or self.rn_in.shape != imgs.shape:
                     self.rn_in = torch.empty_like(imgs, memory_format=torch.contiguous_format)
                     self.rn_graphs = {}
@@ -190,13 +197,13 @@ class CaptionTrainer:
                     # first use: one eager forward (sizes the workspace, and is this batch's forward), then capture
                     # the same call for the following batches (capturing records the launches, it does not run them,
                     # so the BatchNorm running statistics still advance exactly once per batch)
-                    self.resnet.forward(self.rn_in, train_bn=True, out=feats)
+                    self.resnet.forward(self.rn_in, train_bn=True, out=feats, compact=compact)
                     self.side_stream.synchronize()
                     try:
                         g = torch.cuda.CUDAGraph()
                         # thread_local: other threads (e.g. the RCCL watchdog) may keep issuing their own HIP calls
                         with torch.cuda.graph(g, stream=self.side_stream, capture_error_mode="thread_local"):
-                            self.resnet.forward(self.rn_in, train_bn=True, out=feats)
+                            self.resnet.forward(self.rn_in, train_bn=True, out=feats, compact=compact)
                         self.rn_graphs[key] = g
                     except Exception as exc:      # capture unsupported here: stay on eager launches (same results)
                         self.use_graph = False
@@ -209,10 +216,16 @@ class CaptionTrainer:
         self.prefetched = (imgs, feats, done)
 
     # ---- pieces -----------------------------------------------------------------------------
+    def _compact(self, imgs, depth_map) -> bool:
+        """Use the 49-cell layout for this batch? (soft attention, 224x224 RGB and depth inputs)"""
+        return (self.compact_ok and not self.hard and depth_map is not None and tuple(depth_map.shape[-2:]) == (224, 224)
+                and (imgs is None or tuple(imgs.shape[-2:]) == (224, 224)))
+
     def encode(self, imgs: torch.Tensor, depth_map: torch.Tensor, train: bool):
-        feats = self.resnet.forward(imgs, train_bn=train)                                   # depth_train.py:179
+        compact = self._compact(imgs, depth_map)
+        feats = self.resnet.forward(imgs, train_bn=train, compact=compact)                  # depth_train.py:179
         fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), train,
-                                                   workspace=self.enc_ws)                    # :204-206
+                                                   workspace=self.enc_ws, compact=compact)   # :204-206
         self.enc_ws = dtape.workspace
         return feats, fdep, dtape
 
@@ -227,22 +240,25 @@ class CaptionTrainer:
         self.marks = []
         self._mark("start")
         if precomputed_features is None:
+            compact = self._compact(imgs, depth_map)
             if self.prefetched is not None and self.prefetched[0] is imgs:
                 _, feats, done = self.prefetched
                 torch.cuda.current_stream().wait_event(done)
                 self.prefetched = None
+                compact = feats.shape[1] == native.L_COMPACT
             else:
-                feats = self.resnet.forward(imgs, train_bn=True)                            # depth_train.py:179
+                feats = self.resnet.forward(imgs, train_bn=True, compact=compact)           # depth_train.py:179
             if next_imgs is not None:
-                self.prefetch_features(next_imgs)
+                self.prefetch_features(next_imgs, compact=self._compact(next_imgs, depth_map))
             self._mark("resnet152_fwd")
             fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
-                                                       workspace=self.enc_ws)               # :204-206
+                                                       workspace=self.enc_ws, compact=compact)   # :204-206
             self.enc_ws = dtape.workspace
         else:                                       # decoder/depth-encoder-only step (tests)
             feats = precomputed_features
             fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
-                                                       workspace=self.enc_ws)
+                                                       workspace=self.enc_ws,
+                                                       compact=feats.shape[1] == native.L_COMPACT)
             self.enc_ws = dtape.workspace
         self._mark("depth_encoder_fwd")
         if drop_mult is None and self.p_drop > 0:

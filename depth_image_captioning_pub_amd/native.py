@@ -240,10 +240,11 @@ class DepthTape:
     workspace: torch.Tensor
     depth: torch.Tensor
     weights: Dict[str, torch.Tensor]
+    compact: bool = False
 
 
 def depth_encoder_forward(weights: Dict[str, torch.Tensor], state: Dict[str, torch.Tensor], depth: torch.Tensor,
-                          train: bool, workspace: Optional[torch.Tensor] = None):
+                          train: bool, workspace: Optional[torch.Tensor] = None, compact: bool = False):
     """dic_depth_encoder_fwd: depth [B,1,H,W] -> (features [B,196,2048], tape). `state` holds
     bn{1,2,3}.running_{mean,var} (updated in place when train)."""
     lib = _lib.load()
@@ -263,11 +264,19 @@ def depth_encoder_forward(weights: Dict[str, torch.Tensor], state: Dict[str, tor
     need = lib.dic_depth_encoder_workspace_bytes(B, H, W)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=d.device)
-    out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=d.device)
-    rc = lib.dic_depth_encoder_fwd(C.byref(wp), C.byref(st), ptr(d), B, H, W, 1 if train else 0, ptr(out),
-                                   ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
-    check(rc, "dic_depth_encoder_fwd")
-    return out, DepthTape(workspace, d, {k: t for (k, _), t in zip(DEPTH_FIELDS, keep)})
+    if compact:          # the 7x7 map before the 2x2 replication (dic_depth_encoder_fwd_map; 224x224 inputs)
+        if (H, W) != (224, 224):
+            raise _lib.DicError("compact depth features need 224x224 inputs (a 7x7 final map)")
+        out = torch.empty((B, L_COMPACT, D_ENC), dtype=torch.float32, device=d.device)
+        rc = lib.dic_depth_encoder_fwd_map(C.byref(wp), C.byref(st), ptr(d), B, H, W, 1 if train else 0, ptr(out),
+                                           ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+        check(rc, "dic_depth_encoder_fwd_map")
+    else:
+        out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=d.device)
+        rc = lib.dic_depth_encoder_fwd(C.byref(wp), C.byref(st), ptr(d), B, H, W, 1 if train else 0, ptr(out),
+                                       ptr(workspace), C.c_size_t(workspace.numel()), stream_ptr())
+        check(rc, "dic_depth_encoder_fwd")
+    return out, DepthTape(workspace, d, {k: t for (k, _), t in zip(DEPTH_FIELDS, keep)}, compact)
 
 
 def depth_encoder_backward(tape: DepthTape, d_features: torch.Tensor, grads: Optional[Dict[str, torch.Tensor]] = None):
@@ -278,8 +287,11 @@ def depth_encoder_backward(tape: DepthTape, d_features: torch.Tensor, grads: Opt
     wp, keep_w = depth_ptrs(tape.weights)
     df = _dev_f32(d_features, "d_features")
     B, _, H, W = tape.depth.shape
-    rc = lib.dic_depth_encoder_bwd(C.byref(wp), ptr(tape.depth), ptr(df), B, H, W, C.byref(gp), ptr(tape.workspace),
-                                   C.c_size_t(tape.workspace.numel()), stream_ptr())
+    fn = lib.dic_depth_encoder_bwd_map if tape.compact else lib.dic_depth_encoder_bwd
+    if tuple(df.shape) != (B, L_COMPACT if tape.compact else L_CELLS, D_ENC):
+        raise _lib.DicError(f"d_features has shape {tuple(df.shape)}")
+    rc = fn(C.byref(wp), ptr(tape.depth), ptr(df), B, H, W, C.byref(gp), ptr(tape.workspace),
+            C.c_size_t(tape.workspace.numel()), stream_ptr())
     check(rc, "dic_depth_encoder_bwd")
     return grads
 
@@ -340,7 +352,10 @@ class ResNetRunner:
             self.keep.append(tens)
         self.workspace: Optional[torch.Tensor] = None
 
-    def forward(self, imgs: torch.Tensor, train_bn: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, imgs: torch.Tensor, train_bn: bool, out: Optional[torch.Tensor] = None,
+                compact: bool = False) -> torch.Tensor:
+        """compact=True (224x224 inputs): returns the final 7x7 map [B,49,2048] itself instead of its 2x2 replication
+        to [B,196,2048] (dic_resnet_fwd_map) - the input of the compact decoder layout."""
         lib = _lib.load()
         x = _dev_f32(imgs, "imgs")
         B, c, H, W = x.shape
@@ -350,11 +365,16 @@ class ResNetRunner:
         need = lib.dic_resnet_workspace_bytes(B, H, W, self.blocks, self.mode)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        if compact and (H, W) != (224, 224):
+            raise _lib.DicError("compact RGB features need 224x224 inputs (a 7x7 final map)")
+        cells = L_COMPACT if compact else L_CELLS
         if out is None:
-            out = torch.empty((B, L_CELLS, D_ENC), dtype=torch.float32, device=x.device)
-        rc = lib.dic_resnet_fwd(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, self.mode,
-                                ptr(out),
-                                ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
+            out = torch.empty((B, cells, D_ENC), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (B, cells, D_ENC):
+            raise _lib.DicError(f"out must be {(B, cells, D_ENC)}, got {tuple(out.shape)}")
+        fn = lib.dic_resnet_fwd_map if compact else lib.dic_resnet_fwd
+        rc = fn(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, self.mode, ptr(out),
+                ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
         check(rc, "dic_resnet_fwd")
         return out
 

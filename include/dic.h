@@ -175,6 +175,14 @@ int dic_depth_encoder_fwd(const dic_depth_encoder_weights* w, const dic_depth_bn
 int dic_depth_encoder_bwd(const dic_depth_encoder_weights* w, const float* depth, const float* d_features, int B, int H,
                           int W, const dic_depth_encoder_grads* g, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* Depth encoder with the un-replicated output: feature_map [B, P*P, 2048] after BN3 + ReLU (P = 7 at 224x224), and
+ * the matching backward taking the gradient w.r.t. that map (dic_decoder_bwd_cells' d_features). */
+int dic_depth_encoder_fwd_map(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
+                              int H, int W, int train, float* feature_map, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int dic_depth_encoder_bwd_map(const dic_depth_encoder_weights* w, const float* depth, const float* d_feature_map, int B,
+                              int H, int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ---- RGB encoder: CNNEncoder_Atten (Base_caption_model/base_caption_models.py:18-45) = torchvision
  *      ResNet-152 (Bottleneck v1.5; blocks = {3,8,36,3}) minus fc, avgpool -> AdaptiveAvgPool2d(14).
@@ -199,6 +207,11 @@ size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mo
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
                    int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
                    void* stream);
+/* Same, but the output is the network's final feature map itself, [B, (H/32)*(W/32), 2048] (7x7 = 49 cells at
+ * 224x224), without AdaptiveAvgPool2d(14): the input of the compact decoder layout (dic_decoder_fwd_cells). */
+int dic_resnet_fwd_map(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
+                       int H, int W, int train_bn, int mode, float* feature_map, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* ---- fp32-accurate contraction on the bf16 matrix cores (csrc/gemm_bf3.hip): operands are stored as three bf16
  *      planes hi+mid+lo (exact split of fp32), C = A*B^T from 6 exact bf16 products per k accumulated in fp32. */

@@ -161,3 +161,27 @@ def test_prefetch_graph_replay_equals_eager(lib, conv_mode):
     assert s_g.keys() == s_e.keys() and len(s_g) > 0
     for k in s_g:
         assert torch.equal(s_g[k], s_e[k]), k
+
+
+def test_compact_cells_step_equals_reference_layout(lib):
+    """At 224x224 the engine runs the soft-attention step on the 49 distinct annotation cells (7x7 maps, quirk Q3).
+    One full training step (ResNet -> depth encoder -> decoder -> loss -> BPTT -> depth-encoder backward) must give the
+    same loss, alphas and gradients as the reference's 196-cell evaluation of the same batch."""
+    B, vocab, lengths = 3, 40, [8, 6, 5]
+    imgs = syn.rgb_images(B, seed=71).to(DEV)
+    depth = syn.depth_maps(B, seed=72).to(DEV)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=73)
+    caps = caps.to(DEV)
+    drop = syn.dropout_multiplier(B, max(lens) - 1, 0.5, seed=74).to(DEV)
+    res = {}
+    for name, on in (("compact", True), ("full", False)):
+        tr = CaptionTrainer(vocab, device=DEV, resnet_layers=TINY, seed=75, conv_mode="bf16x3")
+        tr.compact_ok = on
+        tr.keep_outputs = True
+        loss = tr.train_step(imgs, depth, caps, lens, drop_mult=drop)
+        torch.cuda.synchronize()
+        res[name] = (float(loss.item()), tr.last["alphas"].clone(), tr.flat.grad.clone(), tr.last["features"].shape[1])
+    assert res["compact"][3] == 49 and res["full"][3] == 196
+    assert abs(res["compact"][0] - res["full"][0]) <= 2e-5 * abs(res["full"][0])
+    _close("alphas", res["compact"][1], res["full"][1], 2e-5)
+    _close("gradients", res["compact"][2], res["full"][2], 3e-4, atol=1e-7)
