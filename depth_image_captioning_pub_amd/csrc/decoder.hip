@@ -726,7 +726,6 @@ static int gemm(int M, int N, int K, GemmOperand A, GemmOperand B, GemmEpilogue 
   return gemm_launch(p, st, tile);
 }
 
-// raw split-K partial slabs [splitk][M][N] (no reduce launch; the consumer kernel sums the slabs)
 // ------------------------------------------------------------------------------------------
 // Compact (49-cell) mode.  At 224x224 both encoders end in a 7x7 map that AdaptiveAvgPool2d(14) replicates 2x2 exactly
 // (quirk Q3), so the 196 annotation cells hold 49 distinct vectors.  Equal scores within a group make
@@ -763,6 +762,7 @@ __global__ void __launch_bounds__(256) fold_dalphas_kernel(const float* __restri
     STMT                                \
   }
 
+// raw split-K partial slabs [splitk][M][N] (no reduce launch; the consumer kernel sums the slabs)
 static int gemm_slabs(int M, int N, int K, GemmOperand A, GemmOperand B, float* slabs, int splitk, hipStream_t st) {
   GemmParams p{};
   p.M = M; p.N = N; p.K = K; p.A = A; p.B = B; p.ep = ep_store(slabs, N); p.splitk = splitk; p.ws = slabs;
@@ -823,7 +823,10 @@ static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* fe
                                              ws.F, ws.mean);)
   DIC_LAUNCH_CHECK();
   // P = Wz F + bz  (hoisted: time-invariant, quirk Q4)
-  DIC_TRY(gemm(B * cells, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st));
+  //   (compact layout: only 98 output tiles at batch 64 -> split K four ways to fill the chip)
+  const int psplit = (cells == kL || (size_t)4 * B * cells * kA > ws.gemm_ws_floats) ? 1 : 4;
+  DIC_TRY(gemm(B * cells, kA, kD, op_rowk(ws.F, kD), op_rowk(w->enc_att_w, kD), ep_store(ws.P, kA, w->enc_att_b), st, psplit,
+               ws.gemm_ws));
   // [h0 | c0] = init_linear(mean)  -> slot 0 of Hall / Call
   {
     GemmEpilogue ep = ep_store(ws.Hall, (long long)(T + 1) * kH, w->init_b);
