@@ -205,8 +205,8 @@ int bn_apply(const float* x, const float* residual, float* y, long long rows, in
 
 // y = act(x*scale + shift (+ residual)) written as three bf16 planes (operand format of the bf16x3 convolution,
 // gemm_bf3.hip: row-pair interleaved, plane_offset(..., 1)) and optionally also as fp32 (block outputs are the next
-// block's identity).  16 consecutive threads produce one 128-B plane line: 8 take 32 channels of pixel 2q, 8 the same
-// channels of pixel 2q+1, so the fp32 reads and the plane writes are both whole cache lines.
+// block's identity).  8 consecutive threads produce one 128-B plane line (4 take the 32 channels of pixel 2q, 4 those of
+// pixel 2q+1; 16-B loads and stores throughout - measured 1 % of the ResNet forward against 8-B plane stores).
 __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                                const unsigned short* __restrict__ rhi,
                                                                const unsigned short* __restrict__ rmid,
@@ -215,41 +215,57 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
                                                                unsigned short* __restrict__ mid,
                                                                unsigned short* __restrict__ lo, long long rows, int C,
                                                                BnBuf bn, int relu) {
-  const long long n4 = ((rows + 1) >> 1) * (C / 2);
+  // one thread = 8 channels of one pixel: 2 x 16-B loads in, one 16-B store per plane out; 8 consecutive threads
+  // produce one 128-B plane line (4 threads per pixel of the pair)
+  const long long n8 = ((rows + 1) >> 1) * (C / 4);
   const int kb = C / 32;
   const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const long long line = i >> 4;
-    const int j = (int)(i & 15);
-    const long long r = (line / kb) * 2 + (j >> 3);
-    const int c = (int)(line % kb) * 32 + (j & 7) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const long long line = i >> 3;
+    const int j = (int)(i & 7);
+    const long long r = (line / kb) * 2 + (j >> 2);
+    const int c = (int)(line % kb) * 32 + (j & 3) * 8;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.f;
     if (r < rows) {
       const long long src = r * C + c;
-      v = *reinterpret_cast<const float4*>(x + src);
-      const float4 s = *reinterpret_cast<const float4*>(bn.scale + c);
-      const float4 t = *reinterpret_cast<const float4*>(bn.shift + c);
-      v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+      const float4 v0 = *reinterpret_cast<const float4*>(x + src), v1 = *reinterpret_cast<const float4*>(x + src + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(bn.scale + c), s1 = *reinterpret_cast<const float4*>(bn.scale + c + 4);
+      const float4 t0 = *reinterpret_cast<const float4*>(bn.shift + c), t1 = *reinterpret_cast<const float4*>(bn.shift + c + 4);
+      v[0] = v0.x * s0.x + t0.x; v[1] = v0.y * s0.y + t0.y; v[2] = v0.z * s0.z + t0.z; v[3] = v0.w * s0.w + t0.w;
+      v[4] = v1.x * s1.x + t1.x; v[5] = v1.y * s1.y + t1.y; v[6] = v1.z * s1.z + t1.z; v[7] = v1.w * s1.w + t1.w;
       if (res) {
-        const float4 q = *reinterpret_cast<const float4*>(res + src);
-        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        const float4 q0 = *reinterpret_cast<const float4*>(res + src), q1 = *reinterpret_cast<const float4*>(res + src + 4);
+        v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
       } else if (rhi) {   // residual given as planes of the same layout: (hi + mid) + lo is the fp32 value, exactly
-        const uint2 a = reinterpret_cast<const uint2*>(rhi)[i], b = reinterpret_cast<const uint2*>(rmid)[i],
-                    d = reinterpret_cast<const uint2*>(rlo)[i];
-        v.x += (__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16)) + __uint_as_float(d.x << 16);
-        v.y += (__uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u)) + __uint_as_float(d.x & 0xffff0000u);
-        v.z += (__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16)) + __uint_as_float(d.y << 16);
-        v.w += (__uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u)) + __uint_as_float(d.y & 0xffff0000u);
+        const uint4 a = reinterpret_cast<const uint4*>(rhi)[i], b = reinterpret_cast<const uint4*>(rmid)[i],
+                    d = reinterpret_cast<const uint4*>(rlo)[i];
+        const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[2 * q] += (__uint_as_float(aw[q] << 16) + __uint_as_float(bw[q] << 16)) + __uint_as_float(dw[q] << 16);
+          v[2 * q + 1] += (__uint_as_float(aw[q] & 0xffff0000u) + __uint_as_float(bw[q] & 0xffff0000u)) +
+                          __uint_as_float(dw[q] & 0xffff0000u);
+        }
       }
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (y) *reinterpret_cast<float4*>(y + src) = v;
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+      }
+      if (y) {
+        *reinterpret_cast<float4*>(y + src) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(y + src + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
     }
-    unsigned short h[4], m[4], l[4];
-    split3_bf16(v.x, h[0], m[0], l[0]); split3_bf16(v.y, h[1], m[1], l[1]);
-    split3_bf16(v.z, h[2], m[2], l[2]); split3_bf16(v.w, h[3], m[3], l[3]);
-    reinterpret_cast<uint2*>(hi)[i] = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    reinterpret_cast<uint2*>(mid)[i] = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-    reinterpret_cast<uint2*>(lo)[i] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    unsigned short h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) split3_bf16(v[q], h[q], m[q], l[q]);
+#define DIC_PK(A_, Q_) ((unsigned)A_[Q_] | ((unsigned)A_[Q_ + 1] << 16))
+    reinterpret_cast<uint4*>(hi)[i] = make_uint4(DIC_PK(h, 0), DIC_PK(h, 2), DIC_PK(h, 4), DIC_PK(h, 6));
+    reinterpret_cast<uint4*>(mid)[i] = make_uint4(DIC_PK(m, 0), DIC_PK(m, 2), DIC_PK(m, 4), DIC_PK(m, 6));
+    reinterpret_cast<uint4*>(lo)[i] = make_uint4(DIC_PK(l, 0), DIC_PK(l, 2), DIC_PK(l, 4), DIC_PK(l, 6));
+#undef DIC_PK
   }
 }
 
@@ -257,7 +273,7 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
                     unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st) {
   DIC_REQUIRE(!(residual && residual_planes), "bn_apply_planes: give the residual as fp32 or as planes, not both");
   DIC_REQUIRE(C % 32 == 0, "bn_apply_planes: C %% 32");
-  const long long n4 = ((rows + 1) >> 1) * (C / 2);
+  const long long n4 = ((rows + 1) >> 1) * (C / 4);      // threads (8 channels each)
   const unsigned short* r0 = residual_planes ? residual_planes[0] : nullptr;
   const unsigned short* r1 = residual_planes ? residual_planes[1] : nullptr;
   const unsigned short* r2 = residual_planes ? residual_planes[2] : nullptr;
