@@ -141,6 +141,9 @@ def main():
                     help="skip the short second measurement with the other ResNet convolution mode")
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not overlap the next batch's frozen ResNet forward with the current step")
+    ap.add_argument("--reference-cells", action="store_true",
+                    help="evaluate the decoder on all 196 annotation cells like the reference (default: the 49 distinct "
+                         "cells of the 7x7 encoder maps - identical results, see DESIGN.md 5.3)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
@@ -178,6 +181,8 @@ def main():
         _lib.load().dic_debug_force_staged_gemm(int(os.environ["DIC_BF3_POLICY"]))
     B = args.batch
     trainer = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=args.conv_mode)
+    if args.reference_cells:
+        trainer.compact_ok = False
     imgs = syn.rgb_images(B, seed=123 + rank).to(dev)
     depth = syn.depth_maps(B, seed=123 + rank).to(dev)
     caps, lens = syn.captions_fixed(B, VOCAB, SEQ_LEN, seed=123 + rank)
@@ -227,6 +232,8 @@ def main():
         del trainer
         torch.cuda.empty_cache()
         tr2 = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=alt_mode)
+        if args.reference_cells:
+            tr2.compact_ok = False
         for _ in range(2):
             tr2.train_step(*step_args, **pipe)
         sync()
