@@ -18,10 +18,14 @@ def timeit(iters=20):
     for _ in range(iters): runner.forward(imgs, train_bn=True, out=out)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-codes = [int(c) for c in sys.argv[1:]] or [0]
+codes = [tuple(int(x) for x in c.split('+')) for c in sys.argv[1:]] or [(0,)]   # 'a+b' applies several switches
+ref_out = None
 for rep in range(4):
     res = []
     for c in codes:
-        lib.dic_debug_force_staged_gemm(c)
-        res.append(f"code {c}: {timeit():.3f} ms")
+        for x in c: lib.dic_debug_force_staged_gemm(x)
+        t = timeit()
+        if ref_out is None: ref_out = out.clone()
+        diff = float((out - ref_out).abs().max() / ref_out.abs().max())
+        res.append(f"code {'+'.join(map(str, c))}: {t:.3f} ms (rel.diff vs first {diff:.1e})")
     print(" | ".join(res), flush=True)
