@@ -246,7 +246,14 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
 /* ---- measurement aid (bench.py roofline): per-launch HIP events around every MFMA contraction launch,
  *      recorded on the launch stream; dic_profile_end synchronises and returns, per kernel instantiation
  *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind; 2000 + 10*A_kind = bf16x3 kernel), total milliseconds, algorithmic FLOPs and launches. */
-/* benchmarking aid: 1 = run every contraction on the register-staged kernel (v1) instead of the LDS-DMA one */
+/* Benchmarking / ablation switches (process-global, used by scripts/ only; results stay correct under every code):
+ *   0 / 1        LDS-DMA kernels (default) / every exact-fp32 contraction on the register-staged kernel (v1)
+ *   11 21 22 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / 128x128 / policy default
+ *   42 43        ring depth 2 / 3 of the 128-wide bf16x3 variants
+ *   50 51 52     bf16x3 64x64 ablation: full / no DMA in the loop / MFMA only
+ *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
+ *   120 121      tail fix-up and BatchNorm finalize in separate launches / fused (default)
+ * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + 2*(tile_m/64 - 1) + (tile_n/64 - 1). */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
