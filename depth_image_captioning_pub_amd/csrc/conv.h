@@ -36,6 +36,11 @@ size_t conv_wgrad_bf3_plane_elems(const ConvDesc& d, int which);
 size_t conv_wgrad_bf3_ws_floats(const ConvDesc& d, int splitk);
 int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk,
                    unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st);
+// 7x7 stride-2 pad-3 stem with C_in = 3 on the bf16x3 kernel (strip formulation, see gemm_bf3.hip)
+size_t conv_stem_bf3_plane_elems(int B, int H, int W);
+int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st);
+int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned short* const x_planes[3],
+                  const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st);
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
                       const unsigned short* const wflip_planes[3], float* dx, hipStream_t st);
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);

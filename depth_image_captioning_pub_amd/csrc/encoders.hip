@@ -118,6 +118,7 @@ struct RnPlan {
   std::vector<RnConv> convs;       // execution order == layer order
   size_t max_act = 0, max_partial = 0, max_red = 0;
   int outH = 0, outW = 0;
+  int B = 0, H = 0, W = 0;         // input batch / image size
 };
 
 static void rn_track(RnPlan& pl, const ConvDesc& d) {
@@ -128,6 +129,7 @@ static void rn_track(RnPlan& pl, const ConvDesc& d) {
 
 static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
   RnPlan pl;
+  pl.B = B; pl.H = H; pl.W = W;
   int li = 0;
   ConvDesc stem{B, H, W, 3, 64, 7, 7, 2, 3, 1};
   pl.convs.push_back({stem, li++});
@@ -161,6 +163,7 @@ static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
 struct RnWs {
   float* act[4];
   unsigned short* planes[3][3];     // bf16x3 mode: three rotating activation buffers x (hi, mid, lo)
+  unsigned short* stem_planes[3];   // bf16x3 mode: zero-padded NHWC4 image planes of the stem (conv_stem_bf3)
   float* partial;
   float* tail;
   double* red;
@@ -175,6 +178,8 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov
   if (mode == 1)
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) w.planes[i][j] = c.take<unsigned short>(pl.max_act + 2048);   // + one pad row (paired layout)
+  if (mode == 1)
+    for (int j = 0; j < 3; ++j) w.stem_planes[j] = c.take<unsigned short>(conv_stem_bf3_plane_elems(pl.B, pl.H, pl.W));
   w.partial = c.take<float>(pl.max_partial);
   w.red = c.take<double>(pl.max_red);
   w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
@@ -194,8 +199,9 @@ static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
+static int g_strip_stem = 1;        // benchmarking (codes 122/123): 0 = stem on the exact-fp32 gather kernel
 static int g_fused_tail_bn = 1;     // benchmarking (codes 120/121): 0 = separate tail fix-up and BN finalize launches
-void resnet_debug_fused_tail_bn(int on) { g_fused_tail_bn = on; }
+void resnet_debug_fused_tail_bn(int on) { if (on >= 2) g_strip_stem = on - 2; else g_fused_tail_bn = on; }
 
 // conv (bf16x3 planes in, raw fp32 out) -> BN scale/shift
 static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, const dic_conv_bn_layer& L, float* y,
@@ -226,6 +232,18 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
   unsigned short* const* P2 = ws.planes[2];
   {   // stem (C_in = 3, 1 % of the FLOPs): exact-fp32 gather kernel, then BN + ReLU + maxpool, then split into planes
     const RnConv& c = pl.convs[ci++];
+    const dic_conv_bn_layer& L0 = layers[c.layer];
+    if (g_strip_stem && L0.w_hi && L0.w_mid && L0.w_lo && c.d.H % 2 == 0 && c.d.W % 2 == 0) {
+      // strip formulation on the bf16x3 kernel (w_hi/mid/lo of layer 0 = dic_resnet_pack_stem_weights)
+      int mtiles = 0;
+      const unsigned short* wp[3] = {L0.w_hi, L0.w_mid, L0.w_lo};
+      DIC_TRY(conv_stem_bf3(imgs_nchw, B, c.d.H, c.d.W, 64, ws.stem_planes, wp, A, train_bn ? ws.partial : nullptr, &mtiles, st));
+      if (train_bn)
+        DIC_TRY(bn_finalize_train(ws.partial, mtiles, c.d.M(), 64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn,
+                                  ws.red, st));
+      else
+        DIC_TRY(bn_finalize_eval(64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn, st));
+    } else
     DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
     DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
     const int ph = (c.d.OH() + 2 - 3) / 2 + 1, pw = (c.d.OW() + 2 - 3) / 2 + 1;
@@ -384,6 +402,13 @@ int dic_depth_encoder_bwd_map(const dic_depth_encoder_weights* w, const float* d
 }
 
 // ---------------------------------------------------------------------------------------------
+int dic_resnet_pack_stem_weights(const float* w_oihw, float* scratch_f32, uint16_t* w_hi, uint16_t* w_mid, uint16_t* w_lo,
+                                 void* stream) {
+  DIC_REQUIRE(w_oihw && scratch_f32 && w_hi && w_mid && w_lo, "resnet_pack_stem_weights: null pointer");
+  unsigned short* wp[3] = {w_hi, w_mid, w_lo};
+  return conv_stem_pack_weights(w_oihw, 64, scratch_f32, wp, (hipStream_t)stream);
+}
+
 int dic_resnet_num_layers(const int* blocks) {
   int n = 1;
   for (int s = 0; s < 4; ++s) n += 3 * blocks[s] + 1;

@@ -82,6 +82,7 @@ struct Bf3Loader {
   static constexpr int NI = BR / 64;
   const unsigned short* p[3];
   int K, C, KW, W, paired;
+  int strip = 0;              // strip mode: elements per padded image row (0 = ordinary im2col)
   int pix0[NI];               // paired im2col: linear input pixel of tap (0,0) (may be negative: masked by tapmask)
   long long lane_off[NI];     // elements
   unsigned tapmask[NI];
@@ -110,6 +111,11 @@ struct Bf3Loader {
         const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
         lane_off[n] = ((long long)img * g.H + ih0) * g.W * g.C + (long long)iw0 * g.C + chunk * 8;
         pix0[n] = (img * g.H + ih0) * g.W + iw0;
+        if (g.nchw == 2) {      // strip mode (7x7 stem on a zero-padded NHWC4 image): K tile kh = the 32 contiguous
+          strip = g.W * g.C;    // elements (8 pixels x 4 channels) of input row ih0 + kh starting at pixel iw0
+          tapmask[n] = valid[n] ? 0xffffffffu : 0u;
+          continue;
+        }
         unsigned m = 0u;
         for (int kh = 0; kh < g.KH; ++kh)
           for (int kw = 0; kw < g.KW; ++kw)
@@ -125,11 +131,16 @@ struct Bf3Loader {
     int tap = 0, dpix = 0;
     long long uni = paired ? (long long)(k0 >> 5) * 64 : (long long)k0;
     if constexpr (KIND == OPK_IM2COL) {
-      tap = k0 / C;
-      const int c0 = k0 - tap * C;
-      const int kh = tap / KW, kw = tap - kh * KW;
-      dpix = kh * W + kw;
-      uni = paired ? (long long)(c0 >> 5) * 64 : ((long long)kh * W + kw) * C + c0;
+      if (strip) {
+        tap = 0;
+        uni = (long long)(k0 >> 5) * strip;
+      } else {
+        tap = k0 / C;
+        const int c0 = k0 - tap * C;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        dpix = kh * W + kw;
+        uni = paired ? (long long)(c0 >> 5) * 64 : ((long long)kh * W + kw) * C + c0;
+      }
     }
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
@@ -138,7 +149,7 @@ struct Bf3Loader {
       else ok = (tapmask[n] >> tap) & 1u;
       long long off = lane_off[n] + uni;
       if constexpr (KIND == OPK_IM2COL) {
-        if (paired) {   // the tap moves the pixel, and with it the half of the 128-B pair line
+        if (paired && !strip) {   // the tap moves the pixel, and with it the half of the 128-B pair line
           const int pix = pix0[n] + dpix;
           off = (long long)(pix >> 1) * (C * 2) + ((pix & 1) << 5) + kchunk[n] + uni;
         }
@@ -530,6 +541,74 @@ int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw
   p.B.kind = OPK_ROWK; p.B.ld = Kpad; p.B.paired = 1;
   p.ep = ep_store(dw_ohwi, d.K(), nullptr, ACT_NONE);
   return launch_bf3(p, st, nullptr, splitk, ws);
+}
+
+// ------------------------------------------------------------------------------------------
+// 7x7 / stride-2 / pad-3 stem (C_in = 3) on the bf16x3 kernel.  The NCHW image is re-laid as zero-padded NHWC4 planes
+// [B][H+6][Wp][4] (Wp = W + 8: 3 px left, 5 right), so that the 7 pixels x 3 channels of filter row kh seen by output
+// (oh, ow) are the first 28 of 32 contiguous, 16-B aligned elements starting at padded pixel (2*oh + kh, 2*ow): one
+// 64-byte strip = one K tile, K = 7 * 32 = 224 (the 8th pixel and the 4th channel meet zero weights).  Replaces the
+// per-element gather of the register-staged kernel (48 TF-eq).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stem_pack_image_kernel(const float* __restrict__ img, int B, int H, int W, int Hp,
+                                                               int Wp, unsigned short* __restrict__ hi,
+                                                               unsigned short* __restrict__ mid,
+                                                               unsigned short* __restrict__ lo) {
+  const long long total = (long long)B * Hp * Wp;         // one thread per padded pixel (4 channels = 8 B per plane)
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int pw = (int)(i % Wp);
+    const long long r = i / Wp;
+    const int ph = (int)(r % Hp);
+    const long long b = r / Hp;
+    const int h = ph - 3, w = pw - 3;
+    unsigned short a[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) split3_bf16(img[((b * 3 + c) * H + h) * W + w], a[c], m[c], l[c]);
+    }
+    reinterpret_cast<uint2*>(hi)[i] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
+    reinterpret_cast<uint2*>(mid)[i] = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    reinterpret_cast<uint2*>(lo)[i] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+
+// stem weights OIHW [CO][3][7][7] -> fp32 [CO][7][8][4] (kw and channel zero-padded), the K order of the strips
+__global__ void __launch_bounds__(256) stem_pack_weights_kernel(const float* __restrict__ w, int CO, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= CO * 224) return;
+  const int c = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, co = i / 224;
+  out[i] = (c < 3 && kw < 7) ? w[((co * 3 + c) * 7 + kh) * 7 + kw] : 0.f;
+}
+
+size_t conv_stem_bf3_plane_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
+
+int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st) {
+  hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(CO * 224, 256)), dim3(256), 0, st, w_oihw, CO, scratch_f32);
+  DIC_LAUNCH_CHECK();
+  return split_bf16x3_paired(scratch_f32, CO, 224, w_planes[0], w_planes[1], w_planes[2], st);
+}
+
+// y_raw[B,OH,OW,CO] = conv7x7s2p3(imgs NCHW) with BN partial sums; x_planes: conv_stem_bf3_plane_elems(B,H,W) each
+int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned short* const x_planes[3],
+                  const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st) {
+  DIC_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_stem_bf3: even image sizes");
+  const int Hp = H + 6, Wp = W + 8, OH = H / 2, OW = W / 2;
+  const long long px = (long long)B * Hp * Wp;
+  hipLaunchKernelGGL(stem_pack_image_kernel, dim3((unsigned)std::min<long long>((px + 255) / 256, 16384)), dim3(256), 0, st,
+                     imgs_nchw, B, H, W, Hp, Wp, x_planes[0], x_planes[1], x_planes[2]);
+  DIC_LAUNCH_CHECK();
+  Bf3Params p{};
+  p.M = B * OH * OW; p.N = CO; p.K = 224;
+  for (int i = 0; i < 3; ++i) { p.A.p[i] = x_planes[i]; p.B.p[i] = w_planes[i]; }
+  p.A.kind = OPK_IM2COL; p.A.ld = 4; p.A.paired = 0;
+  p.A.g = ConvGeom{Hp, Wp, 4, OH, OW, 7, 1, 2, 0, 2};        // nchw = 2: strip mode of the loader
+  p.B.kind = OPK_ROWK; p.B.ld = 224; p.B.paired = 1;
+  p.ep = ep_store(y, CO, nullptr, ACT_NONE);
+  p.ep.stats = bn_partial;
+  DIC_TRY(launch_bf3(p, st, nullptr));
+  if (mtiles_out) *mtiles_out = g_last_mtiles;
+  return DIC_OK;
 }
 
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,

@@ -335,7 +335,15 @@ class ResNetRunner:
             ent = self.table[i]
             ent.w = w_ohwi.data_ptr()
             tens = [w, w_ohwi]
-            if self.mode == 1 and i > 0:             # the C_in = 3 stem stays on the exact-fp32 gather kernel
+            if self.mode == 1 and i == 0 and (co, ci, k) == (64, 3, 7):
+                # 7x7 stem: strip-ordered weight planes [64][7][8][4] for the bf16x3 kernel (dic_resnet_pack_stem_weights)
+                scratch = torch.empty(64 * 224, dtype=torch.float32, device=w.device)
+                planes = [torch.empty(64 * 224, dtype=torch.int16, device=w.device) for _ in range(3)]
+                check(lib.dic_resnet_pack_stem_weights(ptr(w), ptr(scratch), ptr(planes[0]), ptr(planes[1]), ptr(planes[2]),
+                                                       stream_ptr()), "dic_resnet_pack_stem_weights")
+                ent.w_hi, ent.w_mid, ent.w_lo = (pl.data_ptr() for pl in planes)
+                tens += planes + [scratch]
+            if self.mode == 1 and i > 0:             # (other C_in % 32 != 0 layers would stay on the exact-fp32 kernel)
                 planes = [torch.empty(w_ohwi.numel(), dtype=torch.int16, device=w_ohwi.device) for _ in range(3)]
                 check(lib.dic_split_bf16x3_paired(ptr(w_ohwi), C.c_longlong(co), ci * k * k, ptr(planes[0]),
                                                   ptr(planes[1]), ptr(planes[2]), stream_ptr()),

@@ -197,6 +197,12 @@ typedef struct dic_conv_bn_layer {
 } dic_conv_bn_layer;
 
 int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream);
+/* Optional (mode 1): bf16x3 planes of the 7x7 stem weights in the strip order [64][7][8][4] (kw and channel padded with
+ * zeros; row-pair interleaved planes of 64 x 224 elements each).  When layer 0 of the table carries them, the stem runs on
+ * the bf16x3 kernel over a zero-padded NHWC4 copy of the image instead of the exact-fp32 gather kernel.
+ * w_oihw: [64][3][7][7]; scratch_f32: 64*224 floats. */
+int dic_resnet_pack_stem_weights(const float* w_oihw, float* scratch_f32, uint16_t* w_hi, uint16_t* w_mid, uint16_t* w_lo,
+                                 void* stream);
 int dic_resnet_num_layers(const int* blocks);
 size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mode);
 /* imgs [B,3,H,W] NCHW -> features [B,196,2048].  train_bn=1 reproduces quirk Q1 of the reference
@@ -253,6 +259,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   50 51 52     bf16x3 64x64 ablation: full / no DMA in the loop / MFMA only
  *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
  *   120 121      tail fix-up and BatchNorm finalize in separate launches / fused (default)
+ *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + 2*(tile_m/64 - 1) + (tile_n/64 - 1). */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);
