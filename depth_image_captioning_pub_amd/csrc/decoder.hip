@@ -176,6 +176,18 @@ __global__ void __launch_bounds__(128) embed_gather_kernel(const float* __restri
 // row; the HBM-heavy part - one pass over F[b,:,chunk] - is split between them.
 // mode 0: softmax(e); 1: softmax((e+g)/temp); 2: one-hot(argmax(e+g)), g = -log(-log(u)).
 // ------------------------------------------------------------------------------------------
+// LSTM pointwise of the PREVIOUS step, fused into the prologue of attn_fwd (saves one dependent launch per decode
+// step): every chunk-workgroup of row b recomputes h_t from the gate-GEMM slabs of step t-1 (72 loads per thread, one
+// round trip); the chunk-0 workgroup also stores h_t / c_t / the gate activations / the dropped hidden state, exactly
+// what lstm_fwd_kernel(t-1) would have.  Rows that were active at t-1 but not at t get only that part.
+struct FusedLstm {
+  const float* slab;        // [nslab][nb_prev][4H] partial gate pre-activations of step t-1 (null: not fused)
+  const float* bcat;
+  const float* drop;        // dropout multiplier [B][T][H] or null
+  float *Hall_w, *Call, *Gact, *Hdrop;
+  int nslab, nb_prev, nb_cur, packed_off_prev;
+};
+
 template <int L>
 __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float* __restrict__ F, const float* __restrict__ P, const float* __restrict__ Hall,
@@ -183,7 +195,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float* __restrict__ b_full, const float* __restrict__ WbT, const float* __restrict__ b_beta,
     int t, int T, int mode, const float* __restrict__ gumbel_u, int B, float temp,
     float* __restrict__ alphas, float* __restrict__ Qall, float* __restrict__ ctx_all,
-    float* __restrict__ gate_all, float* __restrict__ Xall, int do_gate) {
+    float* __restrict__ gate_all, float* __restrict__ Xall, int do_gate, const FusedLstm fl) {
   // Every phase issues all of its independent loads before the first use (a step is a chain of short phases, each
   // one memory round trip deep): q 32 loads/thread, scores 13 x 16 B, context + gate 2 x (13 x 16 B + 32 x 4 B).
   __shared__ float h_s[kH];
@@ -202,7 +214,42 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long bt = (long long)b * T + t;
 
-  if (tid < kH) h_s[tid] = Hall[((long long)b * (T + 1) + t) * kH + tid];
+  if (fl.slab) {               // h_t = LSTM cell of step t-1 (see FusedLstm)
+    if (b >= fl.nb_cur && chunk != 0) return;              // row finished at t-1: only chunk 0 completes its last cell
+    if (tid < kH) {
+      const int j = tid, tp = t - 1;
+      float pre[4];
+      float v[4][kS_LSTM];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int z = 0; z < kS_LSTM; ++z)
+          v[q][z] = (z < fl.nslab) ? fl.slab[((long long)z * fl.nb_prev + b) * kG + q * kH + j] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float sacc = v[q][0];
+#pragma unroll
+        for (int z = 1; z < kS_LSTM; ++z) sacc += v[q][z];
+        pre[q] = sacc + fl.bcat[q * kH + j];
+      }
+      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      const long long hc = ((long long)b * (T + 1) + tp) * kH + j;
+      const float c = fg * fl.Call[hc] + ig * gg;
+      const float h = og * tanhf(c);
+      h_s[j] = h;
+      if (chunk == 0) {
+        fl.Call[hc + kH] = c;
+        fl.Hall_w[hc + kH] = h;
+        float* ga = fl.Gact + ((long long)b * T + tp) * kG;
+        ga[j] = ig; ga[kH + j] = fg; ga[2 * kH + j] = gg; ga[3 * kH + j] = og;
+        const float dm = fl.drop ? fl.drop[((long long)b * T + tp) * kH + j] : 1.0f;
+        fl.Hdrop[((long long)fl.packed_off_prev + b) * kH + j] = h * dm;
+      }
+    }
+    if (b >= fl.nb_cur) return;                            // (whole workgroup: b is uniform)
+  } else if (tid < kH) {
+    h_s[tid] = Hall[((long long)b * (T + 1) + t) * kH + tid];
+  }
   if (tid >= 256 && tid < 256 + (EP - L)) e_s[L + tid - 256] = 0.f;  // padding cells of the context loop
   __syncthreads();
   {  // q = Wh h + bh   (four quarters of K per output)
@@ -839,14 +886,27 @@ static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* fe
 
   for (int t = 0; t < T; ++t) {
     const int nb = pl.bs[t];
-    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_fwd_kernel<L_>, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.P, ws.Hall,
+    // steps t >= 1 carry the LSTM cell of step t-1 in their prologue (FusedLstm); rows that ended at t-1 are
+    // still in the grid (nb_prev >= nb) for that part only
+    FusedLstm fl{};
+    int rows = nb;
+    if (t > 0) {
+      fl = FusedLstm{ws.slab_g, ws.bcat, drop_mult, ws.Hall, ws.Call, ws.Gact, ws.Hdrop, kS_LSTM, pl.bs[t - 1], nb,
+                     pl.off[t - 1]};
+      rows = pl.bs[t - 1];
+    }
+    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_fwd_kernel<L_>, dim3(kNCH, rows), dim3(512), 0, st, ws.F, ws.P, ws.Hall,
                                                ws.WhT, w->dec_att_b, w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t,
-                                               T, mode, gumbel_u, B, temp, alphas, ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);)
+                                               T, mode, gumbel_u, B, temp, alphas, ws.Qall, ws.ctx, ws.gate, ws.Xall, 1,
+                                               fl);)
     DIC_LAUNCH_CHECK();
     DIC_TRY(gemm_slabs(nb, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(nb), dim3(kH), 0, st, ws.slab_g, kS_LSTM, nb, ws.bcat, t, T, drop_mult,
-                       pl.off[t], ws.Hall, ws.Call, ws.Gact, ws.Hdrop);
+  }
+  if (T > 0) {       // the last step's cell has no following attention launch
+    const int tl = T - 1;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(pl.bs[tl]), dim3(kH), 0, st, ws.slab_g, kS_LSTM, pl.bs[tl], ws.bcat, tl, T,
+                       drop_mult, pl.off[tl], ws.Hall, ws.Call, ws.Gact, ws.Hdrop);
     DIC_LAUNCH_CHECK();
   }
   if (cells != kL) {      // returned attention weights in the reference's 196-cell layout: alpha_cell = beta_group / 4
@@ -1047,7 +1107,7 @@ int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rg
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(kE), 0, st, w->embed, ws.ids, t, T, V, ws.Xall);
     hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, B), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
                        w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, 1.0f, alphas,
-                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1);
+                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1, FusedLstm{});
     DIC_LAUNCH_CHECK();
     DIC_TRY(gemm_slabs(B, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
@@ -1091,7 +1151,7 @@ int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const floa
   hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, B), dim3(512), 0, st, feats, (const float*)P, (const float*)H2,
                      (const float*)WhT, dec_att_b, full_att_w, full_att_b, (const float*)nullptr,
                      (const float*)nullptr, 0, 1, mode, gumbel_u, B, temp, alpha, (float*)nullptr, ctx,
-                     (float*)nullptr, (float*)nullptr, 0);
+                     (float*)nullptr, (float*)nullptr, 0, FusedLstm{});
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
