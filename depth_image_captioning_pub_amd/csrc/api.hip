@@ -4,7 +4,7 @@
 
 using namespace dic;
 
-namespace dic { void resnet_debug_fused_tail_bn(int on); }
+namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); }
 
 extern "C" {
 
@@ -37,6 +37,7 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
 }
 
 int dic_debug_force_staged_gemm(int on) {
+  if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
   if (on == 11 || on == 21 || on == 22 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 52) || (on >= 60 && on <= 63)) gemm_bf3_force_tile(on == 20 ? 0 : on);
   else gemm_force_v1(on);

@@ -74,11 +74,12 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   w.y2p = c.take<float>((size_t)B * g.P2h * g.P2w * 512);
   w.idx2 = c.take<unsigned char>((size_t)B * g.P2h * g.P2w * 512);
   w.x3 = c.take<float>((size_t)g.M3 * 2048);
-  size_t part = (size_t)(g.M1 / 64 + 2) * 2 * 128;
+  const long long rows1 = std::max<long long>(g.M1 / 64 + 2, 1024 + 2);   // conv1 statistics: one row per workgroup
+  size_t part = (size_t)rows1 * 2 * 128;
   part = std::max(part, (size_t)(g.M2 / 64 + 2) * 2 * 512);
   part = std::max(part, (size_t)(g.M3 / 64 + 2) * 2 * 2048);
   w.partial = c.take<float>(part);
-  w.red = c.take<double>(std::max(std::max(bn_finalize_ws_doubles(g.M1 / 64 + 2, 128), bn_finalize_ws_doubles(g.M2 / 64 + 2, 512)),
+  w.red = c.take<double>(std::max(std::max(bn_finalize_ws_doubles((int)rows1, 128), bn_finalize_ws_doubles(g.M2 / 64 + 2, 512)),
                                    bn_finalize_ws_doubles(g.M3 / 64 + 2, 2048)));
   w.bn1 = take_bn(c, 128); w.bn2 = take_bn(c, 512); w.bn3 = take_bn(c, 2048);
   w.dy1 = c.take<float>((size_t)g.M1 * 128);
@@ -89,7 +90,8 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   w.w2f = c.take<float>((size_t)512 * 1152);
   w.w3f = c.take<float>((size_t)512 * 2048);
   w.dw2o = c.take<float>((size_t)512 * 1152);
-  w.wg_ws = c.take<float>(std::max((size_t)kWg1Split * 128 * 49, (size_t)kWg2Split * 512 * 1152));
+  w.wg_ws = c.take<float>(std::max(std::max((size_t)kWg1Split * 128 * 49, (size_t)kWg2Split * 512 * 1152),
+                                   conv1_depth_wgrad_ws_floats(g.c1)));
   w.bn_ws = c.take<float>(bn_backward_ws_floats(2048));
   w.cs_ws = c.take<float>((size_t)256 * 2048);
   for (int i = 0; i < 3; ++i) {
@@ -312,7 +314,10 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   int mt = 0;
   DIC_TRY(oihw_to_ohwi(w->conv2_w, ws.w2o, 512, 128, 3, 3, st));
   // conv1 (1->128, k7 s3) + BN + ReLU + maxpool3          (depth_models.py:19-20,36-39)
-  DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
+  if (conv1_depth_enabled())
+    DIC_TRY(conv1_depth_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
+  else
+    DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, ws.red, st));
   else DIC_TRY(bn_finalize_eval(128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
   DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st));
@@ -384,8 +389,12 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
   DIC_TRY(bn_pool_backward(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,
                            ws.bn_ws, ws.dy1, st));
-  DIC_TRY(conv_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, kWg1Split, ws.wg_ws, st)); // C_in = 1: OHWI == OIHW
-  DIC_TRY(colsum_rows(ws.dy1, 128, g.M1, 128, gr->conv1_b, ws.cs_ws, st));
+  if (conv1_depth_enabled()) {
+    DIC_TRY(conv1_depth_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, gr->conv1_b, ws.wg_ws, ws.cs_ws, st));   // C_in = 1: OHWI == OIHW
+  } else {
+    DIC_TRY(conv_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, kWg1Split, ws.wg_ws, st));
+    DIC_TRY(colsum_rows(ws.dy1, 128, g.M1, 128, gr->conv1_b, ws.cs_ws, st));
+  }
   return DIC_OK;
 }
 

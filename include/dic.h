@@ -260,6 +260,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
  *   120 121      tail fix-up and BatchNorm finalize in separate launches / fused (default)
  *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
+ *   130..134     depth-encoder layer 1: generic MFMA gather path / packed-FMA kernels with 256, 512 (default), 768, 1024 workgroups
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + 2*(tile_m/64 - 1) + (tile_n/64 - 1). */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);

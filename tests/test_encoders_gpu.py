@@ -27,7 +27,12 @@ def _dev(d):
     return {k: v.to(DEV).contiguous() for k, v in d.items()}
 
 
-@pytest.mark.parametrize("B,size,seed", [(2, 224, 51), (3, 100, 52)])
+# sizes: 224 = golden case (73-pixel rows: ragged last pixel group of 1); 100 -> 32 pixels/row (no ragged group); 109 -> 35
+# (ragged 3); 300 / 520 exercise the wider row-prefetch instantiations of the layer-1 weight-gradient kernel (W <= 512,
+# W <= 640).  Seeds of the small maps come from scripts/sweep_depth_seeds.py: with 18..288 samples per channel in layer 3 a
+# ReLU / max-pool decision within ~1e-6 of a tie flips between ANY two fp32 summation orders and moves gradients by
+# percents (seen for the old and the new layer-1 kernels alike); these seeds have no such near-tie.
+@pytest.mark.parametrize("B,size,seed", [(2, 224, 51), (3, 100, 52), (2, 109, 54), (1, 300, 54), (1, 520, 54)])
 def test_depth_encoder_train_fwd_bwd(lib, B, size, seed):
     w, st = syn.depth_encoder_weights(seed=seed)
     # non-trivial BN affine parameters so dgamma/dbeta paths are exercised
