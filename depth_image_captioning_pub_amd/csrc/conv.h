@@ -47,7 +47,6 @@ int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
                         unsigned short* lo, hipStream_t st);
 
-// dW[CO][KH][KW][C] = sum_m dY[m,co] * patch(m)[kh,kw,c]   (split over M with workspace `ws`)
 // Depth-encoder layer 1 (1 -> 128 channels, 7x7, stride 3, no padding) on packed fp32 vector FMAs (conv1_depth.hip).
 //   fwd: y [B,OH,OW,128] = conv(x [B,H,W]) + bias; bn_partial (nullable) receives one [2][128] row of sums per workgroup,
 //        *partial_rows = conv1_depth_fwd_blocks(d) of them
@@ -60,6 +59,7 @@ bool conv1_depth_enabled();     // false only under the benchmarking switch (dic
 size_t conv1_depth_wgrad_ws_floats(const ConvDesc& d);
 int conv1_depth_wgrad(const float* x, const ConvDesc& d, const float* dy, float* dw, float* dbias, float* ws, float* cs_ws,
                       hipStream_t st);
+// dW[CO][KH][KW][C] = sum_m dY[m,co] * patch(m)[kh,kw,c]   (split over M with workspace `ws`)
 int conv_wgrad(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk, float* ws,
                hipStream_t st);
 // dX[B,H,W,C] for stride-1 convolutions: full correlation of dY with the flipped weights

@@ -51,6 +51,8 @@ struct DepthWs {
   float *dy1, *dy1p, *dy2, *dy2p, *dy3, *w2f, *w3f, *dw2o, *wg_ws, *bn_ws, *cs_ws;
   // bf16x3 operands of conv2 (forward and data gradient run on gemm_bf3.hip): planes of pooled1, W2, dY2, flipped W2
   unsigned short *y1p_pl[3], *w2_pl[3], *dy2_pl[3], *w2f_pl[3];
+  unsigned short *y2p_pl[3], *w3_pl[3], *dy3_pl[3], *w3f_pl[3];   // conv3 forward / data gradient operands
+  float* tail;                              // remainder-tile K-split scratch of the bf16x3 launches
   unsigned short *wg_dyT[3], *wg_pT[3];     // weight-gradient operands (transposed planes), shared by conv2 / conv3
   float* wg_bf3_ws;
   size_t bytes;
@@ -99,10 +101,15 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
     w.w2_pl[i] = c.take<unsigned short>((size_t)512 * 1152);
     w.dy2_pl[i] = c.take<unsigned short>((size_t)(g.M2 + 1) * 512);
     w.w2f_pl[i] = c.take<unsigned short>((size_t)128 * 4608);
+    w.y2p_pl[i] = c.take<unsigned short>((size_t)(g.M3 + 1) * 512);
+    w.w3_pl[i] = c.take<unsigned short>((size_t)2048 * 512);
+    w.dy3_pl[i] = c.take<unsigned short>((size_t)(g.M3 + 1) * 2048);
+    w.w3f_pl[i] = c.take<unsigned short>((size_t)512 * 2048);
     w.wg_dyT[i] = c.take<unsigned short>(std::max(conv_wgrad_bf3_plane_elems(g.c2, 0), conv_wgrad_bf3_plane_elems(g.c3, 0)));
     w.wg_pT[i] = c.take<unsigned short>(std::max(conv_wgrad_bf3_plane_elems(g.c2, 1), conv_wgrad_bf3_plane_elems(g.c3, 1)));
   }
   w.wg_bf3_ws = c.take<float>(std::max(conv_wgrad_bf3_ws_floats(g.c2, kWg2SplitBf3), conv_wgrad_bf3_ws_floats(g.c3, kWg3SplitBf3)));
+  w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
   return w;
@@ -334,7 +341,14 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   else DIC_TRY(bn_finalize_eval(512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
   DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st));
   // conv3 (512->2048, k1) + BN + ReLU + AdaptiveAvgPool(14) -> [B,196,2048]   (:23-24,44-47,54)
-  DIC_TRY(conv_fwd(ws.y2p, g.c3, w->conv3_w, w->conv3_b, ws.x3, train ? ws.partial : nullptr, &mt, st));
+  //   on the bf16x3 kernel as well (1x1: OIHW == OHWI, so conv3_w is split as it stands)
+  DIC_TRY(split_bf16x3_paired(ws.y2p, g.M3, 512, ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2], st));
+  DIC_TRY(split_bf16x3_paired(w->conv3_w, 2048, 512, ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2], st));
+  {
+    const unsigned short* xp[3] = {ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2]};
+    const unsigned short* wp[3] = {ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2]};
+    DIC_TRY(conv_fwd_bf3(xp, g.c3, wp, ws.x3, train ? ws.partial : nullptr, &mt, ws.tail, st, w->conv3_b));
+  }
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, ws.red, st));
   else DIC_TRY(bn_finalize_eval(2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
   //   pool_out == 0: BN + ReLU only, output = the [B, P2h*P2w, 2048] map (requires a square map)
@@ -371,7 +385,13 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));   // OHWI == OIHW for 1x1
   DIC_TRY(colsum_rows(ws.dy3, 2048, g.M3, 2048, gr->conv3_b, ws.cs_ws, st));
   DIC_TRY(conv_flip_weights(w->conv3_w, g.c3, ws.w3f, st));
-  DIC_TRY(conv_dgrad_s1(ws.dy3, g.c3, ws.w3f, ws.dy2p, st));
+  DIC_TRY(split_bf16x3_paired(ws.dy3, g.M3, 2048, ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2], st));
+  DIC_TRY(split_bf16x3_paired(ws.w3f, 512, 2048, ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2], st));
+  {
+    const unsigned short* dp[3] = {ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2]};
+    const unsigned short* wp[3] = {ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2]};
+    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c3, wp, ws.dy2p, st));
+  }
   // layer 2
   DIC_TRY(bn_pool_backward(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b,
                            ws.bn_ws, ws.dy2, st));
