@@ -246,6 +246,8 @@ static bool conv1_shape_ok(const ConvDesc& d) {
          d.W <= kC1MaxW;
 }
 
+bool conv1_depth_supported(const ConvDesc& d) { return g_c1_on != 0 && conv1_shape_ok(d); }
+
 int conv1_depth_fwd_blocks(const ConvDesc& d) { return std::min(d.B * d.OH(), g_c1_blocks); }
 
 int conv1_depth_fwd(const float* x, const ConvDesc& d, const float* w, const float* bias, float* y, float* bn_partial,

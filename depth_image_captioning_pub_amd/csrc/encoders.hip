@@ -321,7 +321,7 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   int mt = 0;
   DIC_TRY(oihw_to_ohwi(w->conv2_w, ws.w2o, 512, 128, 3, 3, st));
   // conv1 (1->128, k7 s3) + BN + ReLU + maxpool3          (depth_models.py:19-20,36-39)
-  if (conv1_depth_enabled())
+  if (conv1_depth_supported(g.c1))
     DIC_TRY(conv1_depth_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
   else
     DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
@@ -409,7 +409,7 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
   DIC_TRY(bn_pool_backward(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,
                            ws.bn_ws, ws.dy1, st));
-  if (conv1_depth_enabled()) {
+  if (conv1_depth_supported(g.c1)) {
     DIC_TRY(conv1_depth_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, gr->conv1_b, ws.wg_ws, ws.cs_ws, st));   // C_in = 1: OHWI == OIHW
   } else {
     DIC_TRY(conv_wgrad(depth, g.c1, ws.dy1, gr->conv1_w, kWg1Split, ws.wg_ws, st));

@@ -71,6 +71,27 @@ def test_depth_encoder_train_fwd_bwd(lib, B, size, seed):
             check_packed(gold, "grad." + k, gk, 5e-3, 2e-3 * float(gk.abs().max()))
 
 
+def test_depth_encoder_wide_map_uses_generic_layer1(lib):
+    """Maps wider than the 640-float rows the packed-FMA layer-1 kernels stage in LDS fall back to the generic gather
+    kernels (same results, same API): 52 x 700 map, non-square feature grid pooled to 14 x 14."""
+    w, st = syn.depth_encoder_weights(seed=61)
+    g = torch.Generator().manual_seed(61)
+    depth = torch.rand((1, 1, 52, 700), generator=g)
+    d_out = torch.randn((1, 196, 2048), generator=g) * 1e-2
+    st_ref = {k: v.clone() for k, v in st.items()}
+    wg = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    y_ref = orc.depth_encoder_forward(wg, st_ref, depth, train=True)
+    (y_ref * d_out).sum().backward()
+    st_dev = _dev(st)
+    y, tape = native.depth_encoder_forward(_dev(w), st_dev, depth.to(DEV), train=True)
+    _close("features", y, y_ref, 2e-4)
+    for k in st:
+        _close(k, st_dev[k], st_ref[k], 1e-4)
+    grads = native.depth_encoder_backward(tape, d_out.to(DEV))
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+    _close("grad.conv1.weight", grads["conv1.weight"], wg["conv1.weight"].grad, 5e-3)
+
+
 def test_depth_encoder_eval_mode(lib):
     w, st = syn.depth_encoder_weights(seed=51)
     g = torch.Generator().manual_seed(1)
