@@ -385,6 +385,9 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // K-split + fix-up): 128x64 tiles make it a single round of 392 workgroups at two per CU.  Measured on the whole
   // ResNet forward (scripts/bench_resnet_ab.py 11 20): 15.39 -> 15.18 ms.
   if (t11 >= 512 && t11 < 1024 && p.N <= 256 && p.K >= 512) { tmv = 2; tnv = 1; }
+  // long-K grids of >= 1024 tiles (layer-3/4 shapes at batch 256): 128x64 wins 7..13 % per launch (scripts/bench_bf3_b256.py);
+  // neutral on the batch-64 forward, -0.8 % on the batch-256 forward (scripts/bench_resnet_ab.py --batch 256)
+  if (t11 >= 1024 && p.K >= 1024) { tmv = 2; tnv = 1; }
   if (g_bf3_force == 11) { tmv = 1; tnv = 1; }
   if (g_bf3_force == 21) { tmv = 2; tnv = 1; }
   if (g_bf3_force == 22) { tmv = 2; tnv = 2; }

@@ -1,15 +1,18 @@
-"""Stable A/B of library debug switches on the ResNet-152 forward alone (batch 64, bf16x3, train-mode BN).
-usage: python scripts/bench_resnet_ab.py CODE_A CODE_B [...]   (codes for dic_debug_force_staged_gemm)"""
+"""Stable A/B of library debug switches on the ResNet-152 forward alone (bf16x3, train-mode BN).
+usage: python scripts/bench_resnet_ab.py [--batch N] CODE_A CODE_B [...]   (codes for dic_debug_force_staged_gemm)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+BATCH = 64
+if len(sys.argv) > 2 and sys.argv[1] == '--batch':
+    BATCH = int(sys.argv[2]); del sys.argv[1:3]
 from depth_image_captioning_pub_amd import native, synthetic as syn, _lib
 DEV = "cuda:0"
 lib = _lib.load()
 rn = {k: v.to(DEV) for k, v in syn.resnet152_weights(seed=125).items()}
 runner = native.ResNetRunner(rn, conv_mode="bf16x3")
-imgs = syn.rgb_images(64, seed=123).to(DEV)
-out = torch.empty((64, 196, 2048), device=DEV)
+imgs = syn.rgb_images(BATCH, seed=123).to(DEV)
+out = torch.empty((BATCH, 196, 2048), device=DEV)
 def timeit(iters=20):
     for _ in range(3): runner.forward(imgs, train_bn=True, out=out)
     torch.cuda.synchronize()
