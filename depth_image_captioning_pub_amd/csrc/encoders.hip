@@ -177,6 +177,7 @@ struct RnWs {
   float* tail;
   double* red;
   BnBuf bn;
+  BnBuf bn_ds;                      // statistics of the downsample branch (applied inside the block's last BN pass)
   size_t bytes;
 };
 
@@ -193,6 +194,7 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov
   w.red = c.take<double>(pl.max_red);
   w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
   w.bn = take_bn(c, 2048);
+  w.bn_ds = take_bn(c, 2048);
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
   return w;
@@ -214,20 +216,21 @@ void resnet_debug_fused_tail_bn(int on) { if (on >= 2) g_strip_stem = on - 2; el
 
 // conv (bf16x3 planes in, raw fp32 out) -> BN scale/shift
 static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, const dic_conv_bn_layer& L, float* y,
-                       const RnWs& ws, int train_bn, hipStream_t st) {
+                       const RnWs& ws, int train_bn, hipStream_t st, const BnBuf* bn_out = nullptr) {
+  const BnBuf bn = bn_out ? *bn_out : ws.bn;
   int mtiles = 0;
   const unsigned short* xp[3] = {x_planes[0], x_planes[1], x_planes[2]};
   const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
   int fused = 0;
-  const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, ws.bn.scale, ws.bn.shift, ws.bn.mean, ws.bn.invstd,
+  const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
                       (double)d.M(), kBnEps, kBnMomentum};
   DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st, nullptr,
                        (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused));
   if (train_bn && fused) return DIC_OK;        // statistics were finalized inside the tail fix-up launch
   if (train_bn)
-    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, ws.bn,
+    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn,
                              ws.red, st);
-  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, ws.bn, st);
+  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
 // ResNet forward with the bf16x3 convolution: every activation that feeds a convolution is kept as three bf16 planes
@@ -272,8 +275,8 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       const float* identity = nullptr;
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
-        DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st));
-        DIC_TRY(bn_apply(Cf, nullptr, Cf, ds.d.M(), ds.d.CO, ws.bn, 0, st));
+        // downsample branch: raw output + its own statistics; its BatchNorm is applied where the block output is formed
+        DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st, &ws.bn_ds));
         identity = Cf;
       }
       DIC_TRY(conv_bn_bf3(P2, c3.d, layers[c3.layer], A, ws, train_bn, st));
@@ -283,7 +286,7 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       const unsigned short* idp[3] = {Xp[0], Xp[1], Xp[2]};
       // (pool_out == 0: the final map itself is the output, written in place of the fp32 copy)
       DIC_TRY(bn_apply_planes(A, identity, identity ? nullptr : idp, last ? (pool_out == 0 ? features : X) : nullptr, P1, c3.d.M(), c3.d.CO, ws.bn, 1,
-                              st));
+                              st, identity ? &ws.bn_ds : nullptr));
       std::swap(Xp, P1);
     }
   if (pool_out == 0) return DIC_OK;       // features already hold the [B, outH*outW, 2048] map

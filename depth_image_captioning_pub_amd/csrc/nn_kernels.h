@@ -28,7 +28,8 @@ int bn_apply(const float* x, const float* residual, float* y, long long rows, in
 // same, output as three bf16 planes (hi, mid, lo; exact split of the fp32 value) + optional fp32 copy `y`;
 // the residual may be given as fp32 or as planes of the same layout (reconstructed exactly as (hi + mid) + lo)
 int bn_apply_planes(const float* x, const float* residual, const unsigned short* const residual_planes[3], float* y,
-                    unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st);
+                    unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st,
+                    const BnBuf* residual_bn = nullptr)   /* residual_bn: the fp32 residual is raw, apply this affine first */;
 // y[b,ph,pw,c] = max over kxk window (stride s, pad p) of act(x*scale+shift); idx (nullable) = kh*k+kw of the max
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
                     float* y, unsigned char* idx, hipStream_t st);

@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
                                                                float* __restrict__ y, unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
                                                                unsigned short* __restrict__ lo, long long rows, int C,
-                                                               BnBuf bn, int relu) {
+                                                               BnBuf bn, int relu, const float* __restrict__ rscale,
+                                                               const float* __restrict__ rshift) {
   // one thread = 8 channels of one pixel: 2 x 16-B loads in, one 16-B store per plane out; 8 consecutive threads
   // produce one 128-B plane line (4 threads per pixel of the pair)
   const long long n8 = ((rows + 1) >> 1) * (C / 4);
@@ -236,7 +237,13 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
       v[0] = v0.x * s0.x + t0.x; v[1] = v0.y * s0.y + t0.y; v[2] = v0.z * s0.z + t0.z; v[3] = v0.w * s0.w + t0.w;
       v[4] = v1.x * s1.x + t1.x; v[5] = v1.y * s1.y + t1.y; v[6] = v1.z * s1.z + t1.z; v[7] = v1.w * s1.w + t1.w;
       if (res) {
-        const float4 q0 = *reinterpret_cast<const float4*>(res + src), q1 = *reinterpret_cast<const float4*>(res + src + 4);
+        float4 q0 = *reinterpret_cast<const float4*>(res + src), q1 = *reinterpret_cast<const float4*>(res + src + 4);
+        if (rscale) {     // the residual is a raw convolution output with its own BatchNorm (downsample branch)
+          const float4 a0 = *reinterpret_cast<const float4*>(rscale + c), a1 = *reinterpret_cast<const float4*>(rscale + c + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(rshift + c), b1 = *reinterpret_cast<const float4*>(rshift + c + 4);
+          q0.x = q0.x * a0.x + b0.x; q0.y = q0.y * a0.y + b0.y; q0.z = q0.z * a0.z + b0.z; q0.w = q0.w * a0.w + b0.w;
+          q1.x = q1.x * a1.x + b1.x; q1.y = q1.y * a1.y + b1.y; q1.z = q1.z * a1.z + b1.z; q1.w = q1.w * a1.w + b1.w;
+        }
         v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
       } else if (rhi) {   // residual given as planes of the same layout: (hi + mid) + lo is the fp32 value, exactly
         const uint4 a = reinterpret_cast<const uint4*>(rhi)[i], b = reinterpret_cast<const uint4*>(rmid)[i],
@@ -270,7 +277,9 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
 }
 
 int bn_apply_planes(const float* x, const float* residual, const unsigned short* const residual_planes[3], float* y,
-                    unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st) {
+                    unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st,
+                    const BnBuf* residual_bn) {
+  DIC_REQUIRE(!residual_bn || residual, "bn_apply_planes: residual_bn needs an fp32 residual");
   DIC_REQUIRE(!(residual && residual_planes), "bn_apply_planes: give the residual as fp32 or as planes, not both");
   DIC_REQUIRE(C % 32 == 0, "bn_apply_planes: C %% 32");
   const long long n4 = ((rows + 1) >> 1) * (C / 4);      // threads (8 channels each)
@@ -278,7 +287,8 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
   const unsigned short* r1 = residual_planes ? residual_planes[1] : nullptr;
   const unsigned short* r2 = residual_planes ? residual_planes[2] : nullptr;
   hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, r0, r1, r2, y, planes[0],
-                     planes[1], planes[2], rows, C, bn, relu);
+                     planes[1], planes[2], rows, C, bn, relu, residual_bn ? residual_bn->scale : nullptr,
+                     residual_bn ? residual_bn->shift : nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
