@@ -88,12 +88,16 @@ def pmc_for(rocprof_name: str):
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")))    # newest round last
     try:
+        pmc_for.source = os.path.join("profiles", os.path.basename(paths[-1]))
         for rec in json.load(open(paths[-1])):
             if rocprof_name in rec["kernel"]:
                 return round(rec["hbm_bytes_per_launch_corrected"]), round(rec.get("mfma_util", 0.0), 4) or None
     except Exception:
         pass
     return None, None
+
+
+pmc_for.source = "profiles/ (no PMC summary found)"
 
 
 def cpu_baseline(sample_b: int, iters: int):
@@ -260,7 +264,7 @@ def main():
                     "frac": round(ach / peak, 4), "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic,
                     "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE x2 gfx950 "
-                                    "wide-read correction + WRITE_SIZE, KB->bytes), profiles/r01d_pmc_per_kernel.json (scripts/pmc_summary.py)",
+                                    "wide-read correction + WRITE_SIZE, KB->bytes), " + pmc_for.source + " (scripts/pmc_summary.py)",
                     "mfma_util_pmc": mfma_util,
                     "launches_per_step": top["launches"],
                     "avg_launch_us": round(top["total_ms"] * 1e3 / top["launches"], 2),
