@@ -257,9 +257,8 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
         DIC_TRY(bn_finalize_eval(64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn, st));
     } else
     DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
-    DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, X, nullptr, st));
-    const int ph = (c.d.OH() + 2 - 3) / 2 + 1, pw = (c.d.OW() + 2 - 3) / 2 + 1;
-    DIC_TRY(split_bf16x3_paired(X, (long long)B * ph * pw, 64, Xp[0], Xp[1], Xp[2], st));
+    // BN + ReLU + maxpool straight into the planes of the first bottleneck's input (no fp32 copy, no split pass)
+    DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, nullptr, nullptr, st, Xp));
   }
   for (int s = 0; s < 4; ++s)
     for (int b = 0; b < blocks[s]; ++b) {
@@ -330,10 +329,9 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
     DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, ws.red, st));
   else DIC_TRY(bn_finalize_eval(128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
-  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st));
+  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st, ws.y1p_pl));
   // conv2 (128->512, k3) + BN + ReLU + maxpool3            (:21-22,40-43)
   //   on the bf16x3 kernel (fp32-accurate, ~1.4x the exact-fp32 MFMA rate): split the pooled activations and W2
-  DIC_TRY(split_bf16x3_paired(ws.y1p, (long long)B * g.P1h * g.P1w, 128, ws.y1p_pl[0], ws.y1p_pl[1], ws.y1p_pl[2], st));
   DIC_TRY(split_bf16x3_paired(ws.w2o, 512, 1152, ws.w2_pl[0], ws.w2_pl[1], ws.w2_pl[2], st));
   {
     const unsigned short* xp[3] = {ws.y1p_pl[0], ws.y1p_pl[1], ws.y1p_pl[2]};
@@ -342,10 +340,9 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   }
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M2, 512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, ws.red, st));
   else DIC_TRY(bn_finalize_eval(512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
-  DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st));
+  DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st, ws.y2p_pl));
   // conv3 (512->2048, k1) + BN + ReLU + AdaptiveAvgPool(14) -> [B,196,2048]   (:23-24,44-47,54)
   //   on the bf16x3 kernel as well (1x1: OIHW == OHWI, so conv3_w is split as it stands)
-  DIC_TRY(split_bf16x3_paired(ws.y2p, g.M3, 512, ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2], st));
   DIC_TRY(split_bf16x3_paired(w->conv3_w, 2048, 512, ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2], st));
   {
     const unsigned short* xp[3] = {ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2]};

@@ -32,7 +32,8 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
                     const BnBuf* residual_bn = nullptr)   /* residual_bn: the fp32 residual is raw, apply this affine first */;
 // y[b,ph,pw,c] = max over kxk window (stride s, pad p) of act(x*scale+shift); idx (nullable) = kh*k+kw of the max
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
-                    float* y, unsigned char* idx, hipStream_t st);
+                    float* y, unsigned char* idx, hipStream_t st,
+                    unsigned short* const planes[3] = nullptr)   /* optional: also/only paired bf16x3 planes (y may be null then) */;
 // adaptive average pooling of an NHWC map to OUTxOUT (AdaptiveAvgPool2d(14): exact 2x2 replication for 7x7)
 // with optional fused BN+ReLU on load
 int adaptive_avgpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int out, float* y,

@@ -1,6 +1,7 @@
 // BatchNorm / pooling / elementwise kernels of the CNN encoders (NHWC, fp32). All HBM-bound:
 // 16-byte vector accesses, channel index on the fastest-varying lanes, grid-stride loops.
 #include "nn_kernels.h"
+#include "gemm.h"      // plane_offset (paired bf16x3 plane layout)
 #include <algorithm>
 
 namespace dic {
@@ -299,7 +300,10 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
 __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
                                                                BnBuf bn, int has_bn, int relu, int k, int s, int p,
                                                                int PH, int PW, float* __restrict__ y,
-                                                               unsigned char* __restrict__ idx) {
+                                                               unsigned char* __restrict__ idx,
+                                                               unsigned short* __restrict__ hi,
+                                                               unsigned short* __restrict__ mid,
+                                                               unsigned short* __restrict__ lo) {
   const long long total = (long long)B * PH * PW * C4;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
@@ -331,19 +335,32 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
         if (v.w > best.w) { best.w = v.w; bi.w = id; }
       }
     }
-    reinterpret_cast<float4*>(y)[i] = best;
+    if (y) reinterpret_cast<float4*>(y)[i] = best;
     if (idx) reinterpret_cast<uchar4*>(idx)[i] = bi;
+    if (hi) {     // also (or only) as paired bf16x3 planes: the pooled map feeds a bf16x3 convolution (saves the split pass)
+      const long long row = i / C4;
+      const long long off = plane_offset(row, c4 * 4, C4 / 8, 1);
+      unsigned short h[4], m[4], l[4];
+      split3_bf16(best.x, h[0], m[0], l[0]); split3_bf16(best.y, h[1], m[1], l[1]);
+      split3_bf16(best.z, h[2], m[2], l[2]); split3_bf16(best.w, h[3], m[3], l[3]);
+      *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+      *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    }
   }
 }
 
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
-                    float* y, unsigned char* idx, hipStream_t st) {
+                    float* y, unsigned char* idx, hipStream_t st, unsigned short* const planes[3]) {
   DIC_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+  DIC_REQUIRE(y || planes, "maxpool: no output");
+  DIC_REQUIRE(!planes || C % 32 == 0, "maxpool: plane output needs C %% 32");
   const int PH = (H + 2 * p - k) / s + 1, PW = (W + 2 * p - k) / s + 1;
   const long long total = (long long)B * PH * PW * (C / 4);
   BnBuf z{};
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, B, H, W, C / 4, bn ? *bn : z,
-                     bn ? 1 : 0, relu, k, s, p, PH, PW, y, idx);
+                     bn ? 1 : 0, relu, k, s, p, PH, PW, y, idx, planes ? planes[0] : nullptr, planes ? planes[1] : nullptr,
+                     planes ? planes[2] : nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
