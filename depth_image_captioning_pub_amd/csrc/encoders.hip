@@ -381,11 +381,10 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   // layer 3
   DIC_TRY(adaptive_avgpool_bwd(d_features, B, g.P2h, g.P2w, 2048, pool_out ? pool_out : g.P2h, ws.dy3, st));
   DIC_TRY(relu_mask_bwd(ws.dy3, ws.x3, g.M3, 2048, ws.bn3, st));
-  DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st));
+  DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st, ws.dy3_pl));
   DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));   // OHWI == OIHW for 1x1
   DIC_TRY(colsum_rows(ws.dy3, 2048, g.M3, 2048, gr->conv3_b, ws.cs_ws, st));
   DIC_TRY(conv_flip_weights(w->conv3_w, g.c3, ws.w3f, st));
-  DIC_TRY(split_bf16x3_paired(ws.dy3, g.M3, 2048, ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2], st));
   DIC_TRY(split_bf16x3_paired(ws.w3f, 512, 2048, ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2], st));
   {
     const unsigned short* dp[3] = {ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2]};
@@ -394,12 +393,11 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   }
   // layer 2
   DIC_TRY(bn_pool_backward(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b,
-                           ws.bn_ws, ws.dy2, st));
+                           ws.bn_ws, ws.dy2, st, ws.dy2_pl));
   DIC_TRY(conv_wgrad_bf3(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));
   DIC_TRY(ohwi_to_oihw(ws.dw2o, gr->conv2_w, 512, 128, 3, 3, st));
   DIC_TRY(colsum_rows(ws.dy2, 512, g.M2, 512, gr->conv2_b, ws.cs_ws, st));
   DIC_TRY(conv_flip_weights(ws.w2o, g.c2, ws.w2f, st));
-  DIC_TRY(split_bf16x3_paired(ws.dy2, g.M2, 512, ws.dy2_pl[0], ws.dy2_pl[1], ws.dy2_pl[2], st));
   DIC_TRY(split_bf16x3_paired(ws.w2f, 128, 4608, ws.w2f_pl[0], ws.w2f_pl[1], ws.w2f_pl[2], st));
   {
     const unsigned short* dp[3] = {ws.dy2_pl[0], ws.dy2_pl[1], ws.dy2_pl[2]};

@@ -48,11 +48,13 @@ int maxpool_relu_bwd(const float* dpool, const unsigned char* idx, const float* 
 int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hipStream_t st);
 // BatchNorm backward (train mode): dgamma, dbeta and dx (in place over dy). ws: >= 2*64*C + 3*C floats.
 int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
-                float* dbeta, float* ws, hipStream_t st);
+                float* dbeta, float* ws, hipStream_t st,
+                unsigned short* const dx_planes[3] = nullptr);   /* optional: result also as paired bf16x3 planes */
 // max-pool (non-overlapping k x k) + ReLU + BatchNorm backward in two passes over x, without materialising the pooled
 // gradient (replaces maxpool_relu_bwd + bn_backward); dy receives the gradient w.r.t. the convolution output
 int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
-                     const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st);
+                     const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st,
+                     unsigned short* const dy_planes[3] = nullptr)   /* optional: dy also as paired bf16x3 planes */;
 size_t bn_backward_ws_floats(int C);
 // column sums (bias gradients): out[c] = sum_r X[r*ld + c]
 int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st);

@@ -580,7 +580,10 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ x,
                                                             long long n4, int C4, const float* __restrict__ gamma,
                                                             BnBuf bn, const float* __restrict__ k2,
-                                                            const float* __restrict__ k3) {
+                                                            const float* __restrict__ k3,
+                                                            unsigned short* __restrict__ hi,
+                                                            unsigned short* __restrict__ mid,
+                                                            unsigned short* __restrict__ lo) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c = (int)(i % C4) * 4;
@@ -597,13 +600,22 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ d
     o.z = ga.z * is.z * (g.z - a2.z - (v.z - mu.z) * is.z * a3.z);
     o.w = ga.w * is.w * (g.w - a2.w - (v.w - mu.w) * is.w * a3.w);
     reinterpret_cast<float4*>(dy)[i] = o;
+    if (hi) {     // the same gradient as paired bf16x3 planes (operand of the data-gradient convolution)
+      const long long off = plane_offset(i / C4, c, C4 / 8, 1);
+      unsigned short h[4], m[4], l[4];
+      split3_bf16(o.x, h[0], m[0], l[0]); split3_bf16(o.y, h[1], m[1], l[1]);
+      split3_bf16(o.z, h[2], m[2], l[2]); split3_bf16(o.w, h[3], m[3], l[3]);
+      *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+      *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    }
   }
 }
 
 size_t bn_backward_ws_floats(int C) { return (size_t)kBnChunksMax * 2 * C + 2 * (size_t)C; }
 
 int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
-                float* dbeta, float* ws, hipStream_t st) {
+                float* dbeta, float* ws, hipStream_t st, unsigned short* const dx_planes[3]) {
   DIC_REQUIRE(C % 64 == 0, "bn_backward: C %% 64");
   float* part = ws;
   float* k2 = ws + (size_t)kBnChunksMax * 2 * C;
@@ -613,7 +625,9 @@ int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, chunks, C, (double)rows,
                      dgamma, dbeta, k2, k3);
   const long long n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy_dx, x, n4, C / 4, gamma, bn, k2, k3);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy_dx, x, n4, C / 4, gamma, bn, k2, k3,
+                     dx_planes ? dx_planes[0] : nullptr, dx_planes ? dx_planes[1] : nullptr,
+                     dx_planes ? dx_planes[2] : nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -699,7 +713,10 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
                                                                  long long n4, int C4, PoolGeom pg,
                                                                  const float* __restrict__ gamma, BnBuf bn,
                                                                  const float* __restrict__ k2,
-                                                                 const float* __restrict__ k3) {
+                                                                 const float* __restrict__ k3,
+                                                                 unsigned short* __restrict__ hi,
+                                                                 unsigned short* __restrict__ mid,
+                                                                 unsigned short* __restrict__ lo) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % C4), c = c4 * 4;
@@ -718,11 +735,21 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
     o.z = ga.z * is.z * (g.z - a2.z - (v.z - mu.z) * is.z * a3.z);
     o.w = ga.w * is.w * (g.w - a2.w - (v.w - mu.w) * is.w * a3.w);
     reinterpret_cast<float4*>(dy)[i] = o;
+    if (hi) {     // the same gradient as paired bf16x3 planes (operand of the data-gradient convolution)
+      const long long off = plane_offset(i / C4, c, C4 / 8, 1);
+      unsigned short h[4], m[4], l[4];
+      split3_bf16(o.x, h[0], m[0], l[0]); split3_bf16(o.y, h[1], m[1], l[1]);
+      split3_bf16(o.z, h[2], m[2], l[2]); split3_bf16(o.w, h[3], m[3], l[3]);
+      *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+      *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    }
   }
 }
 
 int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
-                     const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st) {
+                     const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st,
+                     unsigned short* const dy_planes[3]) {
   DIC_REQUIRE(C % 64 == 0, "bn_pool_backward: C %% 64");
   const long long rows = (long long)B * H * W;
   const PoolGeom pg{H, W, k, H / k, W / k};
@@ -736,7 +763,8 @@ int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* 
                      dgamma, dbeta, k2, k3);
   const long long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dpool, idx, x, dy, n4, C / 4, pg,
-                     gamma, bn, k2, k3);
+                     gamma, bn, k2, k3, dy_planes ? dy_planes[0] : nullptr, dy_planes ? dy_planes[1] : nullptr,
+                     dy_planes ? dy_planes[2] : nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
