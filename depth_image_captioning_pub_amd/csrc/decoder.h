@@ -24,6 +24,7 @@ struct DecoderWs {
   float *dHd, *dG, *slab_dx, *dctx, *dgpre, *dq, *dalp, *pbeta, *dqp, *dwf_acc, *dbf_acc, *dPacc, *carry_dc;
   float *dinit, *dmean, *colsum_ws;
   float *alpha_c, *dalpha_c;     // compact (49-cell) mode: group softmax [B,T,49] and its incoming gradient
+  float* dXe;                    // [B,T,E] gradient of the embedded input rows (reduced per token after BPTT)
   int* dlen;
   float* logits_step;
   long long* ids;

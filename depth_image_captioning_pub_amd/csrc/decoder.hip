@@ -64,6 +64,7 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.colsum_ws = c.take<float>((size_t)64 * std::max(std::max(V, kD), kXK));
   w.alpha_c = c.take<float>(BT * kLc);
   w.dalpha_c = c.take<float>(BT * kLc);
+  w.dXe = c.take<float>(BT * kE);
   w.dlen = c.take<int>((size_t)B);
   w.logits_step = c.take<float>((size_t)B * V);
   w.ids = c.take<long long>((size_t)B);
@@ -504,14 +505,12 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
     dctx_all[bt * kD + d] = dcx;
     dctx_s[tid] = dcx;
     dgp_s[tid] = dgp;
-  } else if (chunk == 0 && tid < 256 + kE) {   // d embed[token] += dX[:, 0:E]   (row scatter; <start> rows collide -> atomics)
-    const int e = tid - 256;
+  } else if (chunk == 0 && tid < 256 + kE) {   // gradient of the embedded input row (b, t); summed per token after BPTT
+    const int e = tid - 256;                   // by embed_grad_kernel in a fixed order (no atomics: bit-reproducible)
     float dx = 0.f;
 #pragma unroll
     for (int z = 0; z < kS_DX; ++z) dx += (z < nslab) ? slab_dx[((long long)z * nb + b) * kXK + e] : 0.f;
-    long long id = cap[(long long)b * cap_stride + t];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    atomicAdd(dembed + id * kE + e, dx);
+    dembed[bt * kE + e] = dx;
   }
   __syncthreads();
   // Both remaining parts read long-latency data, so all their loads are issued before the first use:
@@ -561,6 +560,60 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_a_kernel(
   if (tid < kH)
     pbeta[((long long)chunk * B + b) * kH + tid] = (pb_s[0][tid] + pb_s[1][tid]) + (pb_s[2][tid] + pb_s[3][tid]);
   if (tid < L) dalp[((long long)chunk * B + b) * L + tid] = da_s[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// d embed[token] = sum over the decoded rows (b, t) that fed this token, in increasing (b, t) order.  One workgroup
+// (two waves, thread = embedding column) per row n: all rows are tested against n's token 128 at a time, the per-wave
+// ballots go to LDS; the row that is the FIRST occurrence of its token then walks the set bits in order, adds those
+// rows up and stores the result (the table was zeroed before); every other row exits.  No atomics: bit-reproducible.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kE) embed_grad_kernel(const float* __restrict__ dXe, const long long* __restrict__ cap,
+                                                        int cap_stride, const int* __restrict__ dec_len, int B, int T,
+                                                        int V, float* __restrict__ dembed) {
+  extern __shared__ unsigned long long bal_s[];            // [chunks][2 waves]
+  static_assert(kE == 128, "embed_grad_kernel: two waves of 64 columns");
+  const int n = blockIdx.x, N = B * T, e = threadIdx.x, wave = e >> 6;
+  const int bn = n / T, tn = n - bn * T;
+  if (tn >= dec_len[bn]) return;                           // row not decoded (uniform)
+  long long tokl = cap[(long long)bn * cap_stride + tn];
+  const int tok = (int)(tokl < 0 ? 0 : (tokl >= V ? V - 1 : tokl));
+  const int chunks = (N + kE - 1) / kE;
+  for (int c0 = 0; c0 < chunks; c0 += 4) {                   // four chunks' token / length loads in flight together
+    long long idv[4];
+    int lenv[4], tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = min((c0 + u) * kE + e, N - 1);           // clamped: branch-free loads, masked below
+      const int b = m / T;
+      tv[u] = m - b * T;
+      idv[u] = cap[(long long)b * cap_stride + tv[u]];
+      lenv[u] = dec_len[b];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u;
+      long long id = idv[u];
+      id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+      const bool hit = c * kE + e < N && tv[u] < lenv[u] && (int)id == tok;
+      const unsigned long long mask = __ballot(hit);
+      if ((e & 63) == 0 && c < chunks) bal_s[c * 2 + wave] = mask;
+    }
+  }
+  __syncthreads();
+  float acc = 0.f;
+  bool first = true;
+  for (int w2 = 0; w2 < chunks * 2; ++w2) {                // masks in increasing row order
+    unsigned long long mask = bal_s[w2];
+    while (mask) {
+      const int m = w2 * 64 + __builtin_ctzll(mask);
+      if (first && m != n) return;                         // an earlier row carries this token: that row does the sum
+      first = false;
+      acc += dXe[(long long)m * kE + e];
+      mask &= mask - 1;
+    }
+  }
+  dembed[(long long)tok * kE + e] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -995,13 +1048,19 @@ static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* 
     DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_a_kernel<L_>, dim3(kNCH, nb), dim3(512), 0, st, ws.F, ws.slab_dx,
                                                kS_DX, nb, B, t, T, ws.ctx, ws.gate, w->fbeta_w,
                                                (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre, ws.dalp,
-                                               ws.pbeta, g->embed);)
+                                               ws.pbeta, ws.dXe);)
     DIC_LAUNCH_CHECK();
     DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_b_kernel<L_>, dim3(nlch, nb), dim3(256), 0, st, ws.P, ws.Qall, alphas,
                                                ws.dalp, dalphas, w->full_att_w, B, t, T, ws.dlen, inv_temp, ws.dPacc,
                                                ws.dqp, ws.dwf_acc, ws.dbf_acc);)
     DIC_LAUNCH_CHECK();
   }
+  // embedding gradient: per-token sum of the per-row gradients in a fixed order
+  const size_t bal_bytes = (size_t)((B * T + kE - 1) / kE) * 2 * sizeof(unsigned long long);
+  DIC_REQUIRE(bal_bytes <= 60 * 1024, "decoder_bwd: B*T too large for the embedding-gradient kernel");
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(B * T), dim3(kE), bal_bytes, st, ws.dXe,
+                     (const long long*)captions, cap_stride, d_len, B, T, V, g->embed);
+  DIC_LAUNCH_CHECK();
   // gradient of (h0 | c0) and the dq of step 0
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(kH), 0, st, -1, T, B, pl.bs[0], 1, 1, nlch, ws.dHd, 0, drop_mult,
                      ws.slab_dx, kS_DX, pl.bs[0], ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call, ws.carry_dc, ws.dG,

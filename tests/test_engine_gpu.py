@@ -185,3 +185,37 @@ def test_compact_cells_step_equals_reference_layout(lib):
     assert abs(res["compact"][0] - res["full"][0]) <= 2e-5 * abs(res["full"][0])
     _close("alphas", res["compact"][1], res["full"][1], 2e-5)
     _close("gradients", res["compact"][2], res["full"][2], 3e-4, atol=1e-7)
+
+
+def test_full_size_step_properties(lib):
+    """BASELINE configuration C2 at full size (batch 64, 224x224, seq-len 20, V = 10 000, ResNet-152, the oracle would
+    need minutes per step here): size-independent properties of one fused training step.
+      * idempotence: the same step on a fresh trainer gives bit-identical loss and gradients (fixed summation orders);
+      * layout: the compact 49-cell evaluation equals the reference's 196-cell evaluation (loss, gradients);
+      * arithmetic: bf16x3 convolutions give the loss of the exact-fp32 MFMA convolutions within the 1e-4 parity bar."""
+    B, vocab = 64, 10000
+    rn = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(B, seed=123).to(DEV)
+    depth = syn.depth_maps(B, seed=123).to(DEV)
+    caps, lens = syn.captions_fixed(B, vocab, 20, seed=123)
+    caps = caps.to(DEV)
+    drop = syn.dropout_multiplier(B, 20, 0.5, seed=123).to(DEV)
+
+    def step(conv_mode, compact):
+        tr = CaptionTrainer(vocab, device=DEV, seed=123, resnet_init=rn, conv_mode=conv_mode)
+        tr.compact_ok = compact
+        loss = tr.train_step(imgs, depth, caps, lens, drop_mult=drop)
+        torch.cuda.synchronize()
+        out = (float(loss.item()), tr.flat.grad.clone())
+        del tr
+        torch.cuda.empty_cache()
+        return out
+
+    l_a, g_a = step("bf16x3", True)
+    l_b, g_b = step("bf16x3", True)
+    assert np.isfinite(l_a) and l_a == l_b and torch.equal(g_a, g_b), "the fused step is not deterministic"
+    l_full, g_full = step("bf16x3", False)
+    assert abs(l_a - l_full) <= 2e-5 * abs(l_full), (l_a, l_full)
+    _close("gradients compact vs 196 cells", g_a, g_full, 1e-3, atol=1e-7)
+    l_f32, _ = step("fp32", True)
+    assert abs(l_a - l_f32) <= 1e-4, (l_a, l_f32)
