@@ -219,3 +219,34 @@ def test_full_size_step_properties(lib):
     _close("gradients compact vs 196 cells", g_a, g_full, 1e-3, atol=1e-7)
     l_f32, _ = step("fp32", True)
     assert abs(l_a - l_f32) <= 1e-4, (l_a, l_f32)
+
+
+def test_full_size_hard_attention_step_properties(lib):
+    """BASELINE configuration C4 per GPU (depth-hard, batch 32, seq-len 20, V = 10 000, temp 1.0, explicit Gumbel noise):
+    the step is bit-reproducible, its loss is the plain cross-entropy near ln V for random weights, every gradient is
+    finite, and a second step with new noise changes the loss (the noise is really consumed)."""
+    B, vocab, T = 32, 10000, 20
+    rn = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(B, seed=223).to(DEV)
+    depth = syn.depth_maps(B, seed=223).to(DEV)
+    caps, lens = syn.captions_fixed(B, vocab, T, seed=223)
+    caps = caps.to(DEV)
+    drop = syn.dropout_multiplier(B, T, 0.5, seed=223).to(DEV)
+    u1 = syn.gumbel_uniforms(T, B, seed=223).to(DEV)
+    u2 = syn.gumbel_uniforms(T, B, seed=224).to(DEV)
+
+    def step(u):
+        tr = CaptionTrainer(vocab, device=DEV, seed=123, hard=True, resnet_init=rn, conv_mode="bf16x3")
+        loss = tr.train_step(imgs, depth, caps, lens, drop_mult=drop, gumbel_u=u, temp=1.0)
+        torch.cuda.synchronize()
+        out = (float(loss.item()), tr.flat.grad.clone())
+        del tr
+        torch.cuda.empty_cache()
+        return out
+
+    l_a, g_a = step(u1)
+    l_b, g_b = step(u1)
+    assert l_a == l_b and torch.equal(g_a, g_b), "the hard-attention step is not deterministic"
+    assert bool(torch.isfinite(g_a).all()) and abs(l_a - np.log(vocab)) < 1.0, l_a
+    l_c, _ = step(u2)
+    assert np.isfinite(l_c) and l_c != l_a
