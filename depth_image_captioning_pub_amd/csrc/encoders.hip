@@ -43,12 +43,12 @@ constexpr int kWg2SplitBf3 = 5;   // conv2 weight gradient on the bf16x3 kernel:
 constexpr int kWg3SplitBf3 = 3;   // conv3: 256 tiles x 3
 
 struct DepthWs {
-  float *w2o, *x1, *y1p, *x2, *y2p, *x3, *partial;
+  float *x1, *y1p, *x2, *y2p, *x3, *partial;
   double* red;
   unsigned char *idx1, *idx2;
   BnBuf bn1, bn2, bn3;
   // backward
-  float *dy1, *dy1p, *dy2, *dy2p, *dy3, *w2f, *w3f, *dw2o, *wg_ws, *bn_ws, *cs_ws;
+  float *dy1, *dy1p, *dy2, *dy2p, *dy3, *dw2o, *wg_ws, *bn_ws, *cs_ws;
   // bf16x3 operands of conv2 (forward and data gradient run on gemm_bf3.hip): planes of pooled1, W2, dY2, flipped W2
   unsigned short *y1p_pl[3], *w2_pl[3], *dy2_pl[3], *w2f_pl[3];
   unsigned short *y2p_pl[3], *w3_pl[3], *dy3_pl[3], *w3f_pl[3];   // conv3 forward / data gradient operands
@@ -68,7 +68,6 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   Carver c(p, bytes);
   DepthWs w{};
   const long long B = g.B;
-  w.w2o = c.take<float>((size_t)512 * 1152);
   w.x1 = c.take<float>((size_t)g.M1 * 128);
   w.y1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
   w.idx1 = c.take<unsigned char>((size_t)B * g.P1h * g.P1w * 128);
@@ -89,8 +88,6 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   w.dy2 = c.take<float>((size_t)g.M2 * 512);
   w.dy2p = c.take<float>((size_t)B * g.P2h * g.P2w * 512);
   w.dy3 = c.take<float>((size_t)g.M3 * 2048);
-  w.w2f = c.take<float>((size_t)512 * 1152);
-  w.w3f = c.take<float>((size_t)512 * 2048);
   w.dw2o = c.take<float>((size_t)512 * 1152);
   w.wg_ws = c.take<float>(std::max(std::max((size_t)kWg1Split * 128 * 49, (size_t)kWg2Split * 512 * 1152),
                                    conv1_depth_wgrad_ws_floats(g.c1)));
@@ -309,6 +306,39 @@ size_t dic_depth_encoder_workspace_bytes(int B, int H, int W) {
   return depth_carve(nullptr, 0, depth_geom(B, H, W), &ov).bytes;
 }
 
+// All bf16x3 weight operands of the depth encoder in one launch, straight from the OIHW parameters (they are trained, so
+// this runs every step): conv2 / conv3 forward operands [CO][(kh,kw,c)] and the flipped data-gradient operands
+// [C][(KH-1-kh, KW-1-kw, co)], each as paired hi/mid/lo planes.  Replaces seven layout / flip / split launches.
+struct DepthWeightPlanes { unsigned short *w2[3], *w2f[3], *w3[3], *w3f[3]; };
+__global__ void __launch_bounds__(256) depth_prepare_weights_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
+                                                                    DepthWeightPlanes pl) {
+  constexpr int O2 = 512, I2 = 128, O3 = 2048, I3 = 512;
+  constexpr long long n2 = (long long)O2 * I2 * 9, n3 = (long long)O3 * I3;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2 + n3; e += (long long)gridDim.x * 256) {
+    float v;
+    long long off_f, off_b;          // element offsets in the forward / flipped plane sets
+    unsigned short *const *pf, *const *pb;
+    if (e < n2) {                    // conv2_w[o][i][kh][kw]
+      const int kw = (int)(e % 3), kh = (int)((e / 3) % 3), i = (int)((e / 9) % I2), o = (int)(e / (9 * I2));
+      v = w2[e];
+      off_f = plane_offset(o, (kh * 3 + kw) * I2 + i, 9 * I2 / 32, 1);
+      off_b = plane_offset(i, ((2 - kh) * 3 + (2 - kw)) * O2 + o, 9 * O2 / 32, 1);
+      pf = pl.w2; pb = pl.w2f;
+    } else {                         // conv3_w[o][i] (1x1)
+      const long long r = e - n2;
+      const int i = (int)(r % I3), o = (int)(r / I3);
+      v = w3[r];
+      off_f = plane_offset(o, i, I3 / 32, 1);
+      off_b = plane_offset(i, o, O3 / 32, 1);
+      pf = pl.w3; pb = pl.w3f;
+    }
+    unsigned short h, m, l;
+    split3_bf16(v, h, m, l);
+    pf[0][off_f] = h; pf[1][off_f] = m; pf[2][off_f] = l;
+    pb[0][off_b] = h; pb[1][off_b] = m; pb[2][off_b] = l;
+  }
+}
+
 static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_depth_bn_state* s, const float* depth, int B,
                                   int H, int W, int train, float* features, void* workspace, size_t workspace_bytes,
                                   void* stream, int pool_out) {
@@ -321,7 +351,12 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   DepthWs ws = depth_carve(workspace, workspace_bytes, g, &ov);
   DIC_REQUIRE(!ov, "depth_encoder_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
   int mt = 0;
-  DIC_TRY(oihw_to_ohwi(w->conv2_w, ws.w2o, 512, 128, 3, 3, st));
+  {
+    DepthWeightPlanes pl;
+    for (int i = 0; i < 3; ++i) { pl.w2[i] = ws.w2_pl[i]; pl.w2f[i] = ws.w2f_pl[i]; pl.w3[i] = ws.w3_pl[i]; pl.w3f[i] = ws.w3f_pl[i]; }
+    hipLaunchKernelGGL(depth_prepare_weights_kernel, dim3(2048), dim3(256), 0, st, w->conv2_w, w->conv3_w, pl);
+    DIC_LAUNCH_CHECK();
+  }
   // conv1 (1->128, k7 s3) + BN + ReLU + maxpool3          (depth_models.py:19-20,36-39)
   if (conv1_depth_supported(g.c1))
     DIC_TRY(conv1_depth_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
@@ -332,7 +367,6 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st, ws.y1p_pl));
   // conv2 (128->512, k3) + BN + ReLU + maxpool3            (:21-22,40-43)
   //   on the bf16x3 kernel (fp32-accurate, ~1.4x the exact-fp32 MFMA rate): split the pooled activations and W2
-  DIC_TRY(split_bf16x3_paired(ws.w2o, 512, 1152, ws.w2_pl[0], ws.w2_pl[1], ws.w2_pl[2], st));
   {
     const unsigned short* xp[3] = {ws.y1p_pl[0], ws.y1p_pl[1], ws.y1p_pl[2]};
     const unsigned short* wp[3] = {ws.w2_pl[0], ws.w2_pl[1], ws.w2_pl[2]};
@@ -343,7 +377,6 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st, ws.y2p_pl));
   // conv3 (512->2048, k1) + BN + ReLU + AdaptiveAvgPool(14) -> [B,196,2048]   (:23-24,44-47,54)
   //   on the bf16x3 kernel as well (1x1: OIHW == OHWI, so conv3_w is split as it stands)
-  DIC_TRY(split_bf16x3_paired(w->conv3_w, 2048, 512, ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2], st));
   {
     const unsigned short* xp[3] = {ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2]};
     const unsigned short* wp[3] = {ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2]};
@@ -384,8 +417,7 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st, ws.dy3_pl));
   DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));   // OHWI == OIHW for 1x1
   DIC_TRY(colsum_rows(ws.dy3, 2048, g.M3, 2048, gr->conv3_b, ws.cs_ws, st));
-  DIC_TRY(conv_flip_weights(w->conv3_w, g.c3, ws.w3f, st));
-  DIC_TRY(split_bf16x3_paired(ws.w3f, 512, 2048, ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2], st));
+  // (flipped weight planes w3f_pl / w2f_pl were written by the forward's depth_prepare_weights_kernel: same workspace)
   {
     const unsigned short* dp[3] = {ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2]};
     const unsigned short* wp[3] = {ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2]};
@@ -397,8 +429,6 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   DIC_TRY(conv_wgrad_bf3(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));
   DIC_TRY(ohwi_to_oihw(ws.dw2o, gr->conv2_w, 512, 128, 3, 3, st));
   DIC_TRY(colsum_rows(ws.dy2, 512, g.M2, 512, gr->conv2_b, ws.cs_ws, st));
-  DIC_TRY(conv_flip_weights(ws.w2o, g.c2, ws.w2f, st));
-  DIC_TRY(split_bf16x3_paired(ws.w2f, 128, 4608, ws.w2f_pl[0], ws.w2f_pl[1], ws.w2f_pl[2], st));
   {
     const unsigned short* dp[3] = {ws.dy2_pl[0], ws.dy2_pl[1], ws.dy2_pl[2]};
     const unsigned short* wp[3] = {ws.w2f_pl[0], ws.w2f_pl[1], ws.w2f_pl[2]};
