@@ -309,33 +309,48 @@ size_t dic_depth_encoder_workspace_bytes(int B, int H, int W) {
 // All bf16x3 weight operands of the depth encoder in one launch, straight from the OIHW parameters (they are trained, so
 // this runs every step): conv2 / conv3 forward operands [CO][(kh,kw,c)] and the flipped data-gradient operands
 // [C][(KH-1-kh, KW-1-kw, co)], each as paired hi/mid/lo planes.  Replaces seven layout / flip / split launches.
+// Output-major: a thread produces 4 consecutive plane elements (8-B stores, coalesced) from 4 gathered fp32 weights
+// (the 6.5 MB of parameters stay in L2).
 struct DepthWeightPlanes { unsigned short *w2[3], *w2f[3], *w3[3], *w3f[3]; };
 __global__ void __launch_bounds__(256) depth_prepare_weights_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
                                                                     DepthWeightPlanes pl) {
   constexpr int O2 = 512, I2 = 128, O3 = 2048, I3 = 512;
   constexpr long long n2 = (long long)O2 * I2 * 9, n3 = (long long)O3 * I3;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n2 + n3; e += (long long)gridDim.x * 256) {
-    float v;
-    long long off_f, off_b;          // element offsets in the forward / flipped plane sets
-    unsigned short *const *pf, *const *pb;
-    if (e < n2) {                    // conv2_w[o][i][kh][kw]
-      const int kw = (int)(e % 3), kh = (int)((e / 3) % 3), i = (int)((e / 9) % I2), o = (int)(e / (9 * I2));
-      v = w2[e];
-      off_f = plane_offset(o, (kh * 3 + kw) * I2 + i, 9 * I2 / 32, 1);
-      off_b = plane_offset(i, ((2 - kh) * 3 + (2 - kw)) * O2 + o, 9 * O2 / 32, 1);
-      pf = pl.w2; pb = pl.w2f;
-    } else {                         // conv3_w[o][i] (1x1)
-      const long long r = e - n2;
-      const int i = (int)(r % I3), o = (int)(r / I3);
-      v = w3[r];
-      off_f = plane_offset(o, i, I3 / 32, 1);
-      off_b = plane_offset(i, o, O3 / 32, 1);
-      pf = pl.w3; pb = pl.w3f;
+  constexpr long long q2 = n2 / 4, q3 = n3 / 4;              // groups of 4 consecutive elements per plane set
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < 2 * (q2 + q3); e += (long long)gridDim.x * 256) {
+    // set 0: w2 forward, 1: w2 flipped, 2: w3 forward, 3: w3 flipped
+    int set; long long g = e;
+    if (g < q2) set = 0; else if ((g -= q2) < q2) set = 1; else if ((g -= q2) < q3) set = 2; else { g -= q3; set = 3; }
+    const int K = set == 0 ? 9 * I2 : set == 1 ? 9 * O2 : set == 2 ? I3 : O3;
+    const int kb = K / 32;
+    const long long idx = g * 4;                              // linear element index inside the paired plane
+    const long long line = idx >> 6;
+    const int within = (int)(idx & 63);
+    const int row = (int)(line / kb) * 2 + (within >> 5);
+    const int k0 = (int)(line % kb) * 32 + (within & 31);
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u;
+      if (set == 0) {            // row = o, k = (kh*3+kw)*I2 + i
+        const int tap = k / I2, i = k - tap * I2;
+        v[u] = w2[((long long)row * I2 + i) * 9 + tap];
+      } else if (set == 1) {     // row = i, k = ((2-kh)*3 + (2-kw))*O2 + o
+        const int ftap = k / O2, o = k - ftap * O2;
+        v[u] = w2[((long long)o * I2 + row) * 9 + (8 - ftap)];
+      } else if (set == 2) {     // row = o, k = i
+        v[u] = w3[(long long)row * I3 + k];
+      } else {                   // row = i, k = o
+        v[u] = w3[(long long)k * I3 + row];
+      }
     }
-    unsigned short h, m, l;
-    split3_bf16(v, h, m, l);
-    pf[0][off_f] = h; pf[1][off_f] = m; pf[2][off_f] = l;
-    pb[0][off_b] = h; pb[1][off_b] = m; pb[2][off_b] = l;
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) split3_bf16(v[u], h[u], m[u], l[u]);
+    unsigned short* const* pp = set == 0 ? pl.w2 : set == 1 ? pl.w2f : set == 2 ? pl.w3 : pl.w3f;
+    *reinterpret_cast<uint2*>(pp[0] + idx) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(pp[1] + idx) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    *reinterpret_cast<uint2*>(pp[2] + idx) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
   }
 }
 
