@@ -61,7 +61,8 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.carry_dc = c.take<float>((size_t)B * kH);
   w.dinit = c.take<float>((size_t)B * 2 * kH);
   w.dmean = c.take<float>((size_t)B * kD);
-  w.colsum_ws = c.take<float>((size_t)64 * std::max(std::max(V, kD), kXK));
+  // one column sum at a time (V or kXK wide) or the batch of seven bias gradients (sum of their widths, <= 64 rows each)
+  w.colsum_ws = c.take<float>((size_t)64 * std::max(std::max(V, kXK), kG + kD + 3 * kA + 2 * kH + 64));
   w.alpha_c = c.take<float>(BT * kLc);
   w.dalpha_c = c.take<float>(BT * kLc);
   w.dXe = c.take<float>(BT * kE);
@@ -112,6 +113,45 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X
 #pragma unroll 8
   for (int m = blockIdx.y; m < M; m += rs) s += X[(long long)m * ld + n];
   out[(long long)blockIdx.y * N + n] = s;
+}
+
+// Several independent column sums in two launches (the seven bias gradients after BPTT were 14 dependent ~5-us launches).
+// Per job the arithmetic is exactly colsum()'s: `rs` strided partial rows, then their sum in order.
+struct ColsumJob { const float* X; long long ld; int M, N, rs; float* out; float* part; };
+struct ColsumBatch { ColsumJob j[8]; };
+__global__ void __launch_bounds__(256) colsum_batch_kernel(const ColsumBatch b, int stage) {
+  const ColsumJob job = b.j[blockIdx.z];
+  const int n = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (n >= job.N) return;
+  if (stage == 1) {
+    if (y >= job.rs) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int m = y; m < job.M; m += job.rs) s += job.X[(long long)m * job.ld + n];
+    (job.rs > 1 ? job.part : job.out)[(long long)y * job.N + n] = s;
+  } else {
+    if (job.rs == 1 || y != 0) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < job.rs; ++m) s += job.part[(long long)m * job.N + n];
+    job.out[n] = s;
+  }
+}
+
+static int colsum_batch(ColsumBatch& b, int njobs, float* ws, hipStream_t st) {
+  int maxn = 1, maxrs = 1;
+  float* part = ws;
+  for (int i = 0; i < njobs; ++i) {
+    ColsumJob& j = b.j[i];
+    j.rs = std::min(64, std::max(1, j.M / 8));
+    j.part = part;
+    part += (size_t)j.rs * j.N;
+    maxn = std::max(maxn, j.N); maxrs = std::max(maxrs, j.rs);
+  }
+  hipLaunchKernelGGL(colsum_batch_kernel, dim3(ceil_div(maxn, 256), maxrs, njobs), dim3(256), 0, st, b, 1);
+  if (maxrs > 1) hipLaunchKernelGGL(colsum_batch_kernel, dim3(ceil_div(maxn, 256), 1, njobs), dim3(256), 0, st, b, 2);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
 }
 
 static int colsum(const float* X, long long ld, int M, int N, float* out, float* ws, hipStream_t st) {
@@ -1067,6 +1107,18 @@ static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* 
                      ws.dq, ws.dinit);
   DIC_LAUNCH_CHECK();
 
+  // ---- bias gradients: seven column sums in two launches ------------------------------------------
+  {
+    ColsumBatch cb{};
+    cb.j[0] = ColsumJob{ws.dG, kG, (int)BT, kG, 0, g->b_ih, nullptr};
+    cb.j[1] = ColsumJob{ws.dgpre, kD, (int)BT, kD, 0, g->fbeta_b, nullptr};
+    cb.j[2] = ColsumJob{ws.dq, kA, (int)BT, kA, 0, g->dec_att_b, nullptr};
+    cb.j[3] = ColsumJob{ws.dwf_acc, kA, nlch * B, kA, 0, g->full_att_w, nullptr};
+    cb.j[4] = ColsumJob{ws.dbf_acc, 1, nlch * B, 1, 0, g->full_att_b, nullptr};
+    cb.j[5] = ColsumJob{ws.dPacc, kA, B * cells, kA, 0, g->enc_att_b, nullptr};
+    cb.j[6] = ColsumJob{ws.dinit, 2 * kH, B, 2 * kH, 0, g->init_b, nullptr};
+    DIC_TRY(colsum_batch(cb, 7, cs, st));
+  }
   // ---- batched weight gradients ---------------------------------------------------------------
   const float* Hprev = ws.Xall + kE + kD;                     // h_{t-1} rows, ld = kXK
   // LSTM: [dW_ih | dW_hh] = dG^T [X | h_prev]; biases
@@ -1074,23 +1126,16 @@ static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* 
     GemmEpilogue ep = ep_store(g->w_ih, kE + kD);
     ep.C2 = g->w_hh; ep.ldc2 = kH; ep.nsplit = kE + kD;
     DIC_TRY(gemm(kG, kXK, (int)BT, op_colk(ws.dG, kG), op_colk(ws.Xall, kXK), ep, st));
-    DIC_TRY(colsum(ws.dG, kG, (int)BT, kG, g->b_ih, cs, st));
     DIC_CHECK_HIP(hipMemcpyAsync(g->b_hh, g->b_ih, sizeof(float) * kG, hipMemcpyDeviceToDevice, st));
   }
   // f_beta and decoder_att
   DIC_TRY(gemm(kD, kH, (int)BT, op_colk(ws.dgpre, kD), op_colk(Hprev, kXK), ep_store(g->fbeta_w, kH), st));
-  DIC_TRY(colsum(ws.dgpre, kD, (int)BT, kD, g->fbeta_b, cs, st));
   DIC_TRY(gemm(kA, kH, (int)BT, op_colk(ws.dq, kA), op_colk(Hprev, kXK), ep_store(g->dec_att_w, kH), st, 8, ws.gemm_ws));
-  DIC_TRY(colsum(ws.dq, kA, (int)BT, kA, g->dec_att_b, cs, st));
   // full_att
-  DIC_TRY(colsum(ws.dwf_acc, kA, nlch * B, kA, g->full_att_w, cs, st));
-  DIC_TRY(colsum(ws.dbf_acc, 1, nlch * B, 1, g->full_att_b, cs, st));
   // encoder_att: dW_z = dP^T F, db_z = colsum(dP)
   DIC_TRY(gemm(kA, kD, B * cells, op_colk(ws.dPacc, kA), op_colk(ws.F, kD), ep_store(g->enc_att_w, kD), st, 8, ws.gemm_ws));
-  DIC_TRY(colsum(ws.dPacc, kA, B * cells, kA, g->enc_att_b, cs, st));
   // init_linear
   DIC_TRY(gemm(2 * kH, kD, B, op_colk(ws.dinit, 2 * kH), op_colk(ws.mean, kD), ep_store(g->init_w, kD), st));
-  DIC_TRY(colsum(ws.dinit, 2 * kH, B, 2 * kH, g->init_b, cs, st));
   DIC_TRY(gemm(B, kD, 2 * kH, op_rowk(ws.dinit, 2 * kH), op_colk(w->init_w, kD), ep_store(ws.dmean, kD), st, 8,
                ws.gemm_ws, 64));
   // ---- gradient w.r.t. the fused feature map (same for F_rgb and F_depth: F = F_rgb + F_depth) ----
