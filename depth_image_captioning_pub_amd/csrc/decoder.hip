@@ -47,8 +47,8 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.gemm_ws_floats = g;
   w.gemm_ws = c.take<float>(g);
   w.dHd = c.take<float>((size_t)N * kH);
-  w.dG = c.take<float>(BT * kG);
   w.slab_dx = c.take<float>((size_t)kS_DX * B * kXK);
+  w.dG = c.take<float>(BT * kG);           // dG .. dq are adjacent: the backward zeroes them with one memset
   w.dctx = c.take<float>(BT * kD);
   w.dgpre = c.take<float>(BT * kD);
   w.dq = c.take<float>(BT * kA);
@@ -1052,10 +1052,8 @@ static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* 
 
   int* d_len = ws.dlen;
   DIC_CHECK_HIP(hipMemcpyAsync(d_len, dec_lengths, sizeof(int) * B, hipMemcpyHostToDevice, st));
-  DIC_CHECK_HIP(hipMemsetAsync(ws.dG, 0, sizeof(float) * BT * kG, st));
-  DIC_CHECK_HIP(hipMemsetAsync(ws.dgpre, 0, sizeof(float) * BT * kD, st));
-  DIC_CHECK_HIP(hipMemsetAsync(ws.dctx, 0, sizeof(float) * BT * kD, st));
-  DIC_CHECK_HIP(hipMemsetAsync(ws.dq, 0, sizeof(float) * BT * kA, st));
+  // rows that ended early keep zero gradients: dG, dctx, dgpre, dq are carved back to back (decoder_carve)
+  DIC_CHECK_HIP(hipMemsetAsync(ws.dG, 0, (size_t)((char*)(ws.dq + BT * kA) - (char*)ws.dG), st));
   DIC_CHECK_HIP(hipMemsetAsync(g->embed, 0, sizeof(float) * (size_t)V * kE, st));
   float* cs = ws.colsum_ws;
   if (cells != kL) {      // compact layout: beta = group softmax saved by the forward; fold the 196-cell alpha gradient
