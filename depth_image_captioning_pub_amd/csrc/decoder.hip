@@ -465,7 +465,10 @@ __global__ void __launch_bounds__(kH) lstm_fwd_kernel(const float* __restrict__ 
 //   assembled here from step t+1's products:  dX[:,h slot] + W_h^T dq + W_beta^T dgpre.
 //   final=1: only assemble the carry into dinit (gradient of h0 | c0) after step 0.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kH) lstm_bwd_kernel(
+// body: thread j of row b; `active` = this thread takes part (the fused kernel runs it on the first kH of 256 threads);
+// every thread of the workgroup must call it (it contains a barrier)
+__device__ __forceinline__ void lstm_bwd_body(
+    const int b, const int j, const bool active,
     int t, int T, int B, int nb_next, int have_next, int final_pass, int nlch,
     const float* __restrict__ dHd, int packed_off, const float* __restrict__ drop,
     const float* __restrict__ slab_dx, int nslab_dx, int nb_slab, const float* __restrict__ dqp,
@@ -473,16 +476,16 @@ __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
     const float* __restrict__ Gact, const float* __restrict__ Call, float* __restrict__ carry_dc,
     float* __restrict__ dG, float* __restrict__ dq_all, float* __restrict__ dinit) {
   __shared__ float dq_s[kA];
-  const int b = blockIdx.x, j = threadIdx.x;
   float dh = 0.f, dc = 0.f;
   const bool carry = have_next && b < nb_next;          // row b was active at step t+1
-  if (carry) {
+  if (carry && active) {
     float q = 0.f;
     for (int c = 0; c < nlch; ++c) q += dqp[((long long)c * B + b) * kA + j];
     dq_s[j] = q;
     dq_all[((long long)b * T + (t + 1)) * kA + j] = q;
   }
   __syncthreads();
+  if (!active) return;
   if (carry) {
     float s = 0.f;
 #pragma unroll
@@ -513,6 +516,17 @@ __global__ void __launch_bounds__(kH) lstm_bwd_kernel(
   dg[kH + j] = dc * cprev * fg * (1.f - fg);
   dg[2 * kH + j] = dc * ig * (1.f - gg * gg);
   dg[3 * kH + j] = dog * og * (1.f - og);
+}
+
+__global__ void __launch_bounds__(kH) lstm_bwd_kernel(
+    int t, int T, int B, int nb_next, int have_next, int final_pass, int nlch,
+    const float* __restrict__ dHd, int packed_off, const float* __restrict__ drop,
+    const float* __restrict__ slab_dx, int nslab_dx, int nb_slab, const float* __restrict__ dqp,
+    const float* __restrict__ pbeta, const float* __restrict__ W_h /*[A][H]*/,
+    const float* __restrict__ Gact, const float* __restrict__ Call, float* __restrict__ carry_dc,
+    float* __restrict__ dG, float* __restrict__ dq_all, float* __restrict__ dinit) {
+  lstm_bwd_body(blockIdx.x, threadIdx.x, true, t, T, B, nb_next, have_next, final_pass, nlch, dHd, packed_off, drop, slab_dx,
+                nslab_dx, nb_slab, dqp, pbeta, W_h, Gact, Call, carry_dc, dG, dq_all, dinit);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -662,7 +676,8 @@ __global__ void __launch_bounds__(kE) embed_grad_kernel(const float* __restrict_
 // full_att weight/bias gradient accumulators (private per (slice,row): deterministic).
 // ------------------------------------------------------------------------------------------
 template <int L>
-__global__ void __launch_bounds__(256) attn_bwd_b_kernel(
+__device__ __forceinline__ void attn_bwd_b_body(
+    const int lch, const int b,
     const float* __restrict__ P, const float* __restrict__ Qall, const float* __restrict__ alphas,
     const float* __restrict__ dalp, const float* __restrict__ dalphas_in, const float* __restrict__ w_full,
     int B, int t, int T, const int* __restrict__ dec_len, float inv_temp, float* __restrict__ dPacc,
@@ -671,7 +686,6 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
   __shared__ float red_s[4];
   __shared__ float dbf_s[8];
   __shared__ __align__(16) float acc_s[8][2][kA];
-  const int lch = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const long long bt = (long long)b * T + t;
   // BPTT runs t = T-1 .. 0; row b joins at its own last step, where its accumulators are initialised
@@ -747,6 +761,43 @@ __global__ void __launch_bounds__(256) attn_bwd_b_kernel(
     const long long o = (long long)lch * B + b;
     dbf_acc[o] = (first_step ? 0.f : dbf_acc[o]) + s;
   }
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) attn_bwd_b_kernel(
+    const float* __restrict__ P, const float* __restrict__ Qall, const float* __restrict__ alphas,
+    const float* __restrict__ dalp, const float* __restrict__ dalphas_in, const float* __restrict__ w_full,
+    int B, int t, int T, const int* __restrict__ dec_len, float inv_temp, float* __restrict__ dPacc,
+    float* __restrict__ dqp, float* __restrict__ dwf_acc, float* __restrict__ dbf_acc) {
+  attn_bwd_b_body<L>(blockIdx.x, blockIdx.y, P, Qall, alphas, dalp, dalphas_in, w_full, B, t, T, dec_len, inv_temp, dPacc, dqp,
+                     dwf_acc, dbf_acc);
+}
+
+// Compact layout (one score slice per row): the score backward of step t and the LSTM-cell backward of step t-1 (which
+// consumes its dq) in one launch, one workgroup per row that is active at step t-1 (or every row for the closing
+// h0/c0 pass); rows that ended before step t skip the first half.  One dependent launch less per BPTT step.
+struct LstmBwdArgs {
+  int t, T, B, nb_next, have_next, final_pass, nlch;
+  const float* dHd; int packed_off; const float* drop;
+  const float* slab_dx; int nslab_dx, nb_slab; const float* dqp;
+  const float* pbeta; const float* W_h;
+  const float* Gact; const float* Call; float* carry_dc;
+  float* dG; float* dq_all; float* dinit;
+};
+template <int L>
+__global__ void __launch_bounds__(256) attn_bwd_b_lstm_kernel(
+    const float* __restrict__ P, const float* __restrict__ Qall, const float* __restrict__ alphas,
+    const float* __restrict__ dalp, const float* __restrict__ dalphas_in, const float* __restrict__ w_full,
+    int B, int t, int T, const int* __restrict__ dec_len, float inv_temp, float* __restrict__ dPacc,
+    float* __restrict__ dqp, float* __restrict__ dwf_acc, float* __restrict__ dbf_acc, int nb_t, const LstmBwdArgs la) {
+  const int b = blockIdx.x;
+  if (b < nb_t)
+    attn_bwd_b_body<L>(0, b, P, Qall, alphas, dalp, dalphas_in, w_full, B, t, T, dec_len, inv_temp, dPacc, dqp, dwf_acc, dbf_acc);
+  __threadfence_block();             // this row's dq partial (global) is read back by the LSTM half below
+  __syncthreads();
+  lstm_bwd_body(b, threadIdx.x, threadIdx.x < kH, la.t, la.T, la.B, la.nb_next, la.have_next, la.final_pass, la.nlch, la.dHd,
+                la.packed_off, la.drop, la.slab_dx, la.nslab_dx, la.nb_slab, la.dqp, la.pbeta, la.W_h, la.Gact, la.Call,
+                la.carry_dc, la.dG, la.dq_all, la.dinit);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1072,14 +1123,31 @@ static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* 
   DIC_TRY(colsum(dlogits_packed, V, N, V, g->out_b, cs, st));
 
   const float inv_temp = (mode == 1) ? 1.0f / temp : 1.0f;
+  // BPTT.  Per step: LSTM-cell backward (t) -> dX GEMM -> attention backward a -> attention backward b.  In the compact
+  // layout the b half of step t shares its launch with the LSTM-cell backward of step t-1 (attn_bwd_b_lstm_kernel).
+  const bool fuse_b = (nlch == 1);
+  auto lstm_args = [&](int t) {       // arguments of the LSTM-cell backward of step t (t = -1: closing h0/c0 pass)
+    LstmBwdArgs a{};
+    a.T = T; a.B = B; a.nlch = nlch; a.dHd = ws.dHd; a.drop = drop_mult; a.slab_dx = ws.slab_dx; a.nslab_dx = kS_DX;
+    a.dqp = ws.dqp; a.pbeta = ws.pbeta; a.W_h = w->dec_att_w; a.Gact = ws.Gact; a.Call = ws.Call; a.carry_dc = ws.carry_dc;
+    a.dG = ws.dG; a.dq_all = ws.dq; a.dinit = ws.dinit;
+    if (t < 0) { a.t = -1; a.nb_next = pl.bs[0]; a.have_next = 1; a.final_pass = 1; a.packed_off = 0; a.nb_slab = pl.bs[0]; }
+    else {
+      a.t = t; a.have_next = (t + 1 < T); a.nb_next = a.have_next ? pl.bs[t + 1] : 0; a.final_pass = 0;
+      a.packed_off = pl.off[t]; a.nb_slab = a.nb_next;
+    }
+    return a;
+  };
+  auto launch_lstm = [&](int t) {
+    const LstmBwdArgs a = lstm_args(t);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(t < 0 ? B : pl.bs[t]), dim3(kH), 0, st, a.t, a.T, a.B, a.nb_next, a.have_next,
+                       a.final_pass, a.nlch, a.dHd, a.packed_off, a.drop, a.slab_dx, a.nslab_dx, a.nb_slab, a.dqp, a.pbeta,
+                       a.W_h, a.Gact, a.Call, a.carry_dc, a.dG, a.dq_all, a.dinit);
+  };
+  launch_lstm(T - 1);
+  DIC_LAUNCH_CHECK();
   for (int t = T - 1; t >= 0; --t) {
     const int nb = pl.bs[t];
-    const int have_next = (t + 1 < T);
-    const int nb_next = have_next ? pl.bs[t + 1] : 0;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nb), dim3(kH), 0, st, t, T, B, nb_next, have_next, 0, nlch, ws.dHd, pl.off[t],
-                       drop_mult, ws.slab_dx, kS_DX, nb_next, ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call,
-                       ws.carry_dc, ws.dG, ws.dq, ws.dinit);
-    DIC_LAUNCH_CHECK();
     // dX = dG_t * Wcat  (K = 4H)
     DIC_TRY(gemm_slabs(nb, kXK, kG, op_rowk(ws.dG + (long long)t * kG, (long long)T * kG), op_rowk(ws.WcatT, kG),
                        ws.slab_dx, kS_DX, st));
@@ -1088,21 +1156,27 @@ static int decoder_bwd_impl(const dic_decoder_weights* w, int V, const int64_t* 
                                                (const long long*)captions, cap_stride, V, ws.dctx, ws.dgpre, ws.dalp,
                                                ws.pbeta, ws.dXe);)
     DIC_LAUNCH_CHECK();
-    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_b_kernel<L_>, dim3(nlch, nb), dim3(256), 0, st, ws.P, ws.Qall, alphas,
-                                               ws.dalp, dalphas, w->full_att_w, B, t, T, ws.dlen, inv_temp, ws.dPacc,
-                                               ws.dqp, ws.dwf_acc, ws.dbf_acc);)
-    DIC_LAUNCH_CHECK();
+    if (fuse_b) {     // score backward of step t + LSTM-cell backward of step t-1 (t = 0: the closing h0/c0 pass)
+      const LstmBwdArgs la = lstm_args(t - 1);
+      const int rows = t > 0 ? pl.bs[t - 1] : B;
+      DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_b_lstm_kernel<L_>, dim3(rows), dim3(256), 0, st, ws.P, ws.Qall,
+                                                 alphas, ws.dalp, dalphas, w->full_att_w, B, t, T, ws.dlen, inv_temp,
+                                                 ws.dPacc, ws.dqp, ws.dwf_acc, ws.dbf_acc, nb, la);)
+      DIC_LAUNCH_CHECK();
+    } else {
+      DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_bwd_b_kernel<L_>, dim3(nlch, nb), dim3(256), 0, st, ws.P, ws.Qall, alphas,
+                                                 ws.dalp, dalphas, w->full_att_w, B, t, T, ws.dlen, inv_temp, ws.dPacc,
+                                                 ws.dqp, ws.dwf_acc, ws.dbf_acc);)
+      DIC_LAUNCH_CHECK();
+      launch_lstm(t - 1);               // step t-1, or the gradient of (h0 | c0) and the dq of step 0 after t = 0
+      DIC_LAUNCH_CHECK();
+    }
   }
   // embedding gradient: per-token sum of the per-row gradients in a fixed order
   const size_t bal_bytes = (size_t)((B * T + kE - 1) / kE) * 2 * sizeof(unsigned long long);
   DIC_REQUIRE(bal_bytes <= 60 * 1024, "decoder_bwd: B*T too large for the embedding-gradient kernel");
   hipLaunchKernelGGL(embed_grad_kernel, dim3(B * T), dim3(kE), bal_bytes, st, ws.dXe,
                      (const long long*)captions, cap_stride, d_len, B, T, V, g->embed);
-  DIC_LAUNCH_CHECK();
-  // gradient of (h0 | c0) and the dq of step 0
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(kH), 0, st, -1, T, B, pl.bs[0], 1, 1, nlch, ws.dHd, 0, drop_mult,
-                     ws.slab_dx, kS_DX, pl.bs[0], ws.dqp, ws.pbeta, w->dec_att_w, ws.Gact, ws.Call, ws.carry_dc, ws.dG,
-                     ws.dq, ws.dinit);
   DIC_LAUNCH_CHECK();
 
   // ---- bias gradients: seven column sums in two launches ------------------------------------------
