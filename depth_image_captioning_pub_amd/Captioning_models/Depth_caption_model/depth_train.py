@@ -42,6 +42,12 @@ def _synthetic_batches(config, rank: int, n: int, seed0: int):
         yield imgs, depth, caps, lens
 
 
+def _gumbel_draws(tmax: int, batch: int, epoch: int, iteration: int, rank: int, run: int) -> torch.Tensor:
+    """u ~ U(0,1) [T,B,196]: an independent stream per (run, epoch, iteration, rank)."""
+    seed = ((run * 1009 + epoch) * 1000003 + iteration) * 64 + rank
+    return syn.gumbel_uniforms(tmax, batch, seed=seed)
+
+
 def _train(ext, useData, hard: bool, config=None, process_group=None):
     config = config or ConfigTrain()
     if useData != "synthetic":
@@ -64,8 +70,11 @@ def _train(ext, useData, hard: bool, config=None, process_group=None):
         if hard and epoch % config.temp_sch == 0:                       # depth_train.py:481-483
             temp = temp_anneal(epoch)
         window, losses = deque(), []
-        for imgs, depth, caps, lens in _synthetic_batches(config, rank, config.iters_per_epoch, 1000 * epoch):
-            u = syn.gumbel_uniforms(max(lens) - 1, len(lens), seed=epoch).to(dev) if hard else None
+        for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank, config.iters_per_epoch,
+                                                                          1000 * epoch)):
+            # the reference draws a fresh torch.rand(bs, 196) per decode step of every iteration (attention.py:17); here
+            # the T draws of one iteration come as one [T,B,196] tensor from a stream keyed by (epoch, iteration, rank)
+            u = _gumbel_draws(max(lens) - 1, len(lens), epoch, it, rank, int(ext)).to(dev) if hard else None
             loss = trainer.train_step(imgs.to(dev), depth.to(dev), caps.to(dev), lens, gumbel_u=u, temp=float(temp))
             losses.append(loss)                                         # device tensors: no per-iteration host sync
             window.append(loss)
@@ -75,11 +84,14 @@ def _train(ext, useData, hard: bool, config=None, process_group=None):
         if rank == 0:
             with open(train_loss_file, "a") as f:
                 print(f"{epoch}, {train_loss}", file=f)
+        # validation: eval-mode encoders, dropout off; soft = CE + regulariser (depth_train.py:248-292), hard =
+        # decoder.eval_forward (Gumbel-max one-hot attention) with CE only (depth_train.py:555-610)
         val_losses = []
-        if not hard:
-            for imgs, depth, caps, lens in _synthetic_batches(config, rank, max(1, config.iters_per_epoch // 4), 777):
-                val_losses.append(trainer.eval_loss(imgs.to(dev), depth.to(dev), caps.to(dev), lens))
-        val_loss = float(torch.stack(val_losses).mean().item()) if val_losses else train_loss
+        for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank,
+                                                                          max(1, config.iters_per_epoch // 4), 777)):
+            u = _gumbel_draws(max(lens) - 1, len(lens), epoch, 100000 + it, rank, int(ext)).to(dev) if hard else None
+            val_losses.append(trainer.eval_loss(imgs.to(dev), depth.to(dev), caps.to(dev), lens, gumbel_u=u))
+        val_loss = float(torch.stack(val_losses).mean().item())
         history.append((train_loss, val_loss))
         if rank == 0:
             with open(val_loss_file, "a") as f:

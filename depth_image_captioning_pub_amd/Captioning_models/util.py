@@ -1,7 +1,10 @@
 """Host data path with the reference's function names (Captioning_models/util.py:52-221): tokenizer and the two
-collate functions.  String handling stays on the host (it is pure Python in the reference too); the tensor work
-- ImageNet normalisation, the 384x384 bilinear copy for the depth estimator, per-image depth standardisation and
-the depth-cache lookup - runs in libdic_hip.so (csrc/data_ops.hip), so batches are normalised on the GPU."""
+collate functions.  The collate functions are HOST-ONLY (strings, stacking, sorting, padding; CPU tensors out): the
+reference hands them to a DataLoader with num_workers=4 (depth_train.py:93, config.py:65) and forked workers cannot
+touch the GPU.  The tensor work the reference does inside its collate - ImageNet normalisation and the 384x384 bilinear
+copy for the depth estimator (util.py:100-101) - runs in libdic_hip.so (csrc/data_ops.hip) once the batch has arrived in
+the training process: `device_transforms(raw_imgs.to(device))`; likewise per-image depth standardisation and the
+depth-cache lookup."""
 from __future__ import annotations
 
 import ctypes as C
@@ -85,30 +88,34 @@ def _pad_batch(captions: Sequence[torch.Tensor], null_id: int):
     return targets, lengths
 
 
-def collate_func(batch: Sequence[Tuple[Union[torch.Tensor, Sequence[str]]]], word_to_id: Dict[str, int],
-                 device: str = "cuda:0"):
+def collate_func(batch: Sequence[Tuple[Union[torch.Tensor, Sequence[str]]]], word_to_id: Dict[str, int]):
     """(imgs, targets, lengths): one of the 5 captions at random, sorted by length (descending), padded with
-    '<null>' (util.py:57-78).  Images are stacked and moved to `device`; like the reference this collate does not
-    normalise them (base_train.py does that in its T.Compose)."""
+    '<null>' (util.py:57-78).  Host only, CPU tensors; like the reference this collate does not normalise the images
+    (base_train.py does that in its T.Compose)."""
     imgs, captions = zip(*batch)
     captions = [tokenize_caption(random.choice(cap), word_to_id) for cap in captions]
     order = sorted(range(len(captions)), key=lambda i: len(captions[i]), reverse=True)
-    imgs = torch.stack([imgs[i] for i in order]).to(device)
+    imgs = torch.stack([imgs[i] for i in order])
     targets, lengths = _pad_batch([captions[i] for i in order], word_to_id["<null>"])
     return imgs, targets, lengths
 
 
-def collate_func_for_dep(batch: Sequence[Tuple[Union[torch.Tensor, Sequence[str]]]], word_to_id: Dict[str, int],
-                         device: str = "cuda:0"):
-    """(imgs, imgs_for_dep, targets, lengths, allcaps) as util.py:80-110; the ImageNet normalisation and the 384x384
-    copy for the depth estimator are produced on the GPU."""
+def collate_func_for_dep(batch: Sequence[Tuple[Union[torch.Tensor, Sequence[str]]]], word_to_id: Dict[str, int]):
+    """(imgs, imgs_for_dep, targets, lengths, allcaps) with the reference's arity and order (util.py:80-110), host only.
+    Both image slots hold the SAME un-normalised CPU stack [B,3,H,W] in [0,1]: the reference's two transforms
+    (util.py:100-101) are applied on the GPU by the training loop, `imgs, imgs_for_dep = device_transforms(raw.to(dev))`."""
     imgs, captions = zip(*batch)
     allcaps = [" ".join(cap) for cap in captions]
     captions = [tokenize_caption(random.choice(cap), word_to_id) for cap in captions]
     order = sorted(range(len(captions)), key=lambda i: len(captions[i]), reverse=True)
-    raw = torch.stack([imgs[i] for i in order]).to(device)
+    raw = torch.stack([imgs[i] for i in order])
     targets, lengths = _pad_batch([captions[i] for i in order], word_to_id["<null>"])
-    return norm_trans(raw), dep_trans(raw), targets, lengths, [allcaps[i] for i in order]
+    return raw, raw, targets, lengths, [allcaps[i] for i in order]
+
+
+def device_transforms(raw_imgs: torch.Tensor):
+    """norm_trans + dep_trans of a raw GPU batch (util.py:13-17,100-101) -> (imgs [B,3,H,W], imgs_for_dep [B,3,384,384])."""
+    return norm_trans(raw_imgs), dep_trans(raw_imgs)
 
 
 class DepthCache:
@@ -122,9 +129,11 @@ class DepthCache:
 
     def put(self, keys: Sequence[str], depth_maps: torch.Tensor) -> None:
         for i, k in enumerate(keys):
-            s = self.slot.setdefault(k, len(self.slot))
-            if s >= self.table.shape[0]:
-                raise _lib.DicError("DepthCache is full")
+            s = self.slot.get(k)
+            if s is None:
+                if len(self.slot) >= self.table.shape[0]:
+                    raise _lib.DicError("DepthCache is full")          # (checked before the key is registered)
+                s = self.slot[k] = len(self.slot)
             self.table[s].copy_(depth_maps[i])
 
     def get(self, keys: Sequence[str]) -> torch.Tensor:

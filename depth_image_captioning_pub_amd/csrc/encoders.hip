@@ -473,6 +473,26 @@ int dic_depth_encoder_bwd_map(const dic_depth_encoder_weights* w, const float* d
   return depth_encoder_bwd_impl(w, depth, d_feature_map, B, H, W, gr, workspace, workspace_bytes, stream, 0);
 }
 
+// Diagnostic: copy out the selections of the last forward on this workspace (see include/dic.h).
+int dic_depth_encoder_inspect(const void* workspace, size_t workspace_bytes, int B, int H, int W, int which, void* out,
+                              long long* n_out, void* stream) {
+  DIC_REQUIRE(workspace && B > 0 && which >= 1 && which <= 5, "depth_encoder_inspect: bad arguments");
+  const DepthGeom g = depth_geom(B, H, W);
+  bool ov = false;
+  DepthWs ws = depth_carve(const_cast<void*>(workspace), workspace_bytes, g, &ov);
+  DIC_REQUIRE(!ov, "depth_encoder_inspect: workspace too small");
+  const long long n = which <= 2 ? (long long)B * g.P1h * g.P1w * 128
+                      : which <= 4 ? (long long)B * g.P2h * g.P2w * 512 : g.M3 * 2048;
+  if (n_out) *n_out = n;
+  if (!out) return DIC_OK;
+  if (which == 5) return relu_mask_export(ws.x3, g.M3, 2048, ws.bn3, (unsigned char*)out, (hipStream_t)stream);
+  const void* src = which == 1 ? (const void*)ws.y1p : which == 2 ? (const void*)ws.idx1 : which == 3 ? (const void*)ws.y2p
+                                                                                                      : (const void*)ws.idx2;
+  const size_t bytes = (size_t)n * ((which & 1) ? sizeof(float) : 1);
+  DIC_CHECK_HIP(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DIC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 int dic_resnet_pack_stem_weights(const float* w_oihw, float* scratch_f32, uint16_t* w_hi, uint16_t* w_mid, uint16_t* w_lo,
                                  void* stream) {

@@ -56,6 +56,8 @@ int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* 
                      const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st,
                      unsigned short* const dy_planes[3] = nullptr)   /* optional: dy also as paired bf16x3 planes */;
 size_t bn_backward_ws_floats(int C);
+// diagnostic: out[r*C + c] = 1 where relu_mask_bwd keeps the gradient (BN output > 0), else 0
+int relu_mask_export(const float* x, long long rows, int C, BnBuf bn, unsigned char* out, hipStream_t st);
 // column sums (bias gradients): out[c] = sum_r X[r*ld + c]
 int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st);
 // layout transforms for weights: OIHW <-> OHWI

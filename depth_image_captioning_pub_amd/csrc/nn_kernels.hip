@@ -489,6 +489,9 @@ int maxpool_relu_bwd(const float* dpool, const unsigned char* idx, const float* 
   return DIC_OK;
 }
 
+// BN + ReLU decision of one element: the fused multiply-add the forward kernels contract `v * scale + shift` into
+__device__ __forceinline__ bool relu_passes(float v, float sc, float sh) { return fmaf(v, sc, sh) > 0.f; }
+
 __global__ void __launch_bounds__(256) relu_mask_bwd_kernel(float* __restrict__ dy, const float* __restrict__ x,
                                                              long long n4, int C4, BnBuf bn) {
   const long long stride = (long long)gridDim.x * 256;
@@ -498,12 +501,28 @@ __global__ void __launch_bounds__(256) relu_mask_bwd_kernel(float* __restrict__ 
     const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
     float4 g = reinterpret_cast<float4*>(dy)[i];
-    if (!(v.x * sc.x + sh.x > 0.f)) g.x = 0.f;
-    if (!(v.y * sc.y + sh.y > 0.f)) g.y = 0.f;
-    if (!(v.z * sc.z + sh.z > 0.f)) g.z = 0.f;
-    if (!(v.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+    if (!relu_passes(v.x, sc.x, sh.x)) g.x = 0.f;
+    if (!relu_passes(v.y, sc.y, sh.y)) g.y = 0.f;
+    if (!relu_passes(v.z, sc.z, sh.z)) g.z = 0.f;
+    if (!relu_passes(v.w, sc.w, sh.w)) g.w = 0.f;
     reinterpret_cast<float4*>(dy)[i] = g;
   }
+}
+
+// diagnostic (dic_depth_encoder_inspect): the ReLU decisions exactly as relu_mask_bwd_kernel takes them
+__global__ void __launch_bounds__(256) relu_mask_export_kernel(const float* __restrict__ x, long long n, int C, BnBuf bn,
+                                                                unsigned char* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int c = (int)(i % C);
+    out[i] = relu_passes(x[i], bn.scale[c], bn.shift[c]) ? 1 : 0;
+  }
+}
+
+int relu_mask_export(const float* x, long long rows, int C, BnBuf bn, unsigned char* out, hipStream_t st) {
+  hipLaunchKernelGGL(relu_mask_export_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, st, x, rows * C, C, bn, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
 }
 
 int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hipStream_t st) {

@@ -9,9 +9,12 @@ namespace dic {
 
 // ---- cross-entropy forward + backward, one workgroup per packed token ------------------------
 // loss_row = logsumexp(x) - x[target]; dlogits = (softmax(x) - onehot) * gscale   (gscale = 1/N)
-__global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* __restrict__ logits,
+// `dlogits` MAY ALIAS `logits` (in-place gradient): neither pointer is __restrict__.  (They were in round 1: the compiler
+// was then free to sink thread 0's read of x[target] below the barrier, where another thread may already have stored
+// that element's gradient - the row's loss, and only the loss, came out wrong whenever the timing allowed it.)
+__global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* logits,
                                                           const long long* __restrict__ targets, int V, float gscale,
-                                                          float* __restrict__ loss_rows, float* __restrict__ dlogits) {
+                                                          float* __restrict__ loss_rows, float* dlogits) {
   __shared__ float red[8];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* x = logits + (long long)row * V;
@@ -29,10 +32,13 @@ __global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* __restrict
   s = red[4] + red[5] + red[6] + red[7];
   const float lse = m + logf(s);
   long long tg = targets[row];
+  // F.cross_entropy raises on a class index outside [0, V) (depth_train.py:214); a kernel cannot raise, so the row's
+  // loss becomes NaN - the step's loss is then NaN, which no caller can mistake for a result - and the address is clamped
+  const bool bad_target = tg < 0 || tg >= V;
   tg = tg < 0 ? 0 : (tg >= V ? V - 1 : tg);
-  const float xt = x[tg];
-  __syncthreads();                       // dlogits may alias logits: every read of x[tg] is done
-  if (tid == 0) loss_rows[row] = lse - xt;
+  if (tid == 0) loss_rows[row] = bad_target ? __builtin_nanf("") : lse - x[tg];
+  __threadfence_block();
+  __syncthreads();                       // dlogits may alias logits: the read of x[tg] is done before any store below
   float* dx = dlogits + (long long)row * V;
   for (int v = tid; v < V; v += 256) {
     const float p = expf(x[v] - lse);
@@ -77,11 +83,27 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const float* __restric
   if (threadIdx.x == 0) loss[0] = (float)red[0];
 }
 
+// one workgroup per decode step t: rows with dec_len > t are a prefix (lengths sorted descending), their packed offset
+// is sum_{t' < t} bs[t'] = sum_b min(dec_len[b], t).  Both counts are recomputed per workgroup from the device copy of
+// the lengths, so no host-built table has to be staged.
 __global__ void __launch_bounds__(256) pack_targets_kernel(const long long* __restrict__ cap, int cap_stride,
-                                                            const int* __restrict__ off, const int* __restrict__ bs,
+                                                            const int* __restrict__ dec_len, int B,
                                                             long long* __restrict__ out) {
-  const int t = blockIdx.x;
-  for (int b = threadIdx.x; b < bs[t]; b += 256) out[off[t] + b] = cap[(long long)b * cap_stride + t + 1];
+  __shared__ int red[2][4];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int off = 0, nb = 0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const int l = dec_len[b];
+    off += min(l, t);
+    nb += l > t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); nb += __shfl_xor(nb, o, 64); }
+  if (lane == 0) { red[0][w] = off; red[1][w] = nb; }
+  __syncthreads();
+  off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  nb = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  for (int b = threadIdx.x; b < nb; b += 256) out[off + b] = cap[(long long)b * cap_stride + t + 1];
 }
 
 // ---- AdamW (torch.optim.AdamW single-tensor math, fp32) -----------------------------------------
@@ -138,21 +160,21 @@ using namespace dic;
 extern "C" {
 
 int dic_caption_loss(const float* logits, const int64_t* targets, int n_packed, int V, const float* alphas, int B,
-                     int Tmax, float lam, float grad_scale, float* loss, float* dlogits, float* dalphas,
-                     float* scratch, void* stream) {
+                     int Tmax, float lam, float ce_grad_scale, float reg_grad_scale, float* loss, float* dlogits,
+                     float* dalphas, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DIC_REQUIRE(logits && targets && loss && dlogits && scratch, "caption_loss: null pointer");
   DIC_REQUIRE(n_packed > 0 && V > 0, "caption_loss: empty input");
   float* loss_rows = scratch;
   float* reg_rows = scratch + n_packed;
   hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(n_packed), dim3(256), 0, st, logits, (const long long*)targets, V,
-                     grad_scale / (float)n_packed, loss_rows, dlogits);
+                     ce_grad_scale / (float)n_packed, loss_rows, dlogits);
   DIC_LAUNCH_CHECK();
   float reg_scale = 0.f;
   if (alphas) {
     DIC_REQUIRE(dalphas != nullptr && B > 0 && Tmax > 0, "caption_loss: dalphas required with alphas");
     reg_scale = lam / ((float)B * (float)DIC_L);
-    hipLaunchKernelGGL(alpha_reg_kernel, dim3(B), dim3(256), 0, st, alphas, Tmax, reg_scale * grad_scale, reg_rows,
+    hipLaunchKernelGGL(alpha_reg_kernel, dim3(B), dim3(256), 0, st, alphas, Tmax, reg_scale * reg_grad_scale, reg_rows,
                        dalphas);
     DIC_LAUNCH_CHECK();
   }
@@ -168,17 +190,18 @@ int dic_pack_targets(const int64_t* captions, int cap_stride, const int* dec_len
   DIC_REQUIRE(captions && dec_lengths && targets && B > 0, "pack_targets: bad arguments");
   const int T = dec_lengths[0];
   DIC_REQUIRE(T >= 1 && T < 4096, "pack_targets: bad length");
-  std::vector<int> tab(2 * T);
-  int off = 0;
-  for (int t = 0; t < T; ++t) {
-    int nb = 0;
-    for (int b = 0; b < B; ++b) nb += dec_lengths[b] > t;
-    tab[t] = off; tab[T + t] = nb; off += nb;
+  long long off = 0;
+  for (int b = 0; b < B; ++b) {
+    DIC_REQUIRE(dec_lengths[b] >= 1 && (b == 0 || dec_lengths[b] <= dec_lengths[b - 1]),
+                "pack_targets: lengths must be >= 1 and sorted in descending order");
+    off += dec_lengths[b];
   }
-  int* d_tab = reinterpret_cast<int*>(targets + off);       // staged in the tail (see include/dic.h)
-  DIC_CHECK_HIP(hipMemcpyAsync(d_tab, tab.data(), sizeof(int) * 2 * T, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(pack_targets_kernel, dim3(T), dim3(256), 0, st, (const long long*)captions, cap_stride, d_tab,
-                     d_tab + T, (long long*)targets);
+  // the caller's `dec_lengths` array is only read during this call: hipMemcpyAsync from pageable host memory returns
+  // after the bytes have been staged, and nothing function-local is handed to the copy engine
+  int* d_len = reinterpret_cast<int*>(targets + off);       // device copy of the lengths lives in the tail (include/dic.h)
+  DIC_CHECK_HIP(hipMemcpyAsync(d_len, dec_lengths, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(pack_targets_kernel, dim3(T), dim3(256), 0, st, (const long long*)captions, cap_stride, d_len, B,
+                     (long long*)targets);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

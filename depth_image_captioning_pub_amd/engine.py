@@ -8,7 +8,9 @@ training), same loss, same AdamW update - every tensor operation runs in libdic_
 Data parallelism (not in the reference): one process per GPU, each rank takes a slice of
 the batch; the 29 gradient tensors live in one flat fp32 buffer that is all-reduced (sum of gradients that
 were pre-scaled by 1/world_size) with RCCL over xGMI - the decoder bucket is launched as soon as BPTT ends and
-overlaps the depth-encoder backward; BatchNorm statistics stay per rank (DDP semantics).
+overlaps the depth-encoder backward; BatchNorm statistics stay per rank (DDP semantics).  The cross-entropy gradient of
+rank r is weighted by its share of the packed tokens (N_r / sum_r N_r), so the all-reduced sum is the gradient of the
+global token mean also for variable-length captions; the attention regulariser is a mean over [B, L] and is weighted 1/N.
 """
 from __future__ import annotations
 
@@ -109,6 +111,7 @@ class CaptionTrainer:
         self.vocab, self.lr, self.hard, self.p_drop, self.lam = vocab, lr, hard, dropout, lam
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         dec = decoder_init if decoder_init is not None else syn.decoder_weights(vocab, seed=seed)
         if depth_init is None:
             depth_init, depth_state = syn.depth_encoder_weights(seed=seed + 1)
@@ -128,8 +131,12 @@ class CaptionTrainer:
         self.rn_w = {k: v.to(self.device).contiguous() for k, v in rn.items()}
         self.resnet = native.ResNetRunner(self.rn_w, resnet_layers, conv_mode=conv_mode)
         self.step_count = 0
+        self.depth_fwd_count = 0       # train-mode depth-encoder forwards (= BatchNorm num_batches_tracked)
         self.rng_offset = 0
         self.seed = seed
+        # every rank draws its own dropout masks: the rank is mixed into the Philox key (same key on all ranks would
+        # apply one mask pattern to every shard of the global batch)
+        self.drop_seed = (seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
         self.dec_ws: Optional[torch.Tensor] = None
         self.enc_ws: Optional[torch.Tensor] = None
         self.last = {}
@@ -139,6 +146,7 @@ class CaptionTrainer:
         self.feat_bufs = [None, None]
         self.feat_flip = 0
         self.prefetched = None         # (imgs tensor, features, done-event)
+        self.side_done = None          # completion event of the newest side-stream ResNet forward (see _resnet_eager)
         # the prefetched forward is ~620 launches (9 ms of host enqueue per step); it is captured once per
         # (batch shape, output buffer) into a hipGraph and replayed (0.2 ms), so the main stream's work is enqueued
         # right away instead of 9 ms into the step.  DIC_RESNET_GRAPH=0 keeps eager launches.
@@ -187,7 +195,10 @@ class CaptionTrainer:
             if not self.use_graph:
                 self.resnet.forward(imgs, train_bn=True, out=feats, compact=compact)
             else:
-                key = (tuple(imgs.shape), i, compact)
+                ws = self.resnet.workspace
+                # a graph holds raw pointers: it is only valid for the workspace it was captured with (an eager forward
+                # of a larger batch re-allocates it), so the workspace address is part of the key
+                key = (tuple(imgs.shape), i, compact, ws.data_ptr() if ws is not None else 0)
                 if self.rn_in is None or self.rn_in.shape != imgs.shape:
                     self.rn_in = torch.empty_like(imgs, memory_format=torch.contiguous_format)
                     self.rn_graphs = {}
@@ -199,6 +210,8 @@ class CaptionTrainer:
                     # so the BatchNorm running statistics still advance exactly once per batch)
                     self.resnet.forward(self.rn_in, train_bn=True, out=feats, compact=compact)
                     self.side_stream.synchronize()
+                    key = key[:3] + (self.resnet.workspace.data_ptr(),)      # (the eager call may have sized it)
+                    self.rn_graphs = {k: v for k, v in self.rn_graphs.items() if k[3] == key[3]}
                     try:
                         g = torch.cuda.CUDAGraph()
                         # thread_local: other threads (e.g. the RCCL watchdog) may keep issuing their own HIP calls
@@ -211,9 +224,19 @@ class CaptionTrainer:
                         self.last["resnet_graph_error"] = repr(exc)
                 else:
                     g.replay()
+                    self.resnet.train_forwards += 1
             done = torch.cuda.Event()
             done.record(self.side_stream)
         self.prefetched = (imgs, feats, done)
+        self.side_done = done
+
+    def _resnet_eager(self, imgs: torch.Tensor, train_bn: bool, compact: bool) -> torch.Tensor:
+        """ResNet forward on the CURRENT stream.  The runner has one workspace and one set of BatchNorm running
+        statistics, shared with the side-stream prefetch: first wait for the newest side-stream forward (a later
+        prefetch waits for this call through its `ready` event), so the two never run concurrently."""
+        if self.side_done is not None:
+            torch.cuda.current_stream().wait_event(self.side_done)
+        return self.resnet.forward(imgs, train_bn=train_bn, compact=compact)
 
     # ---- pieces -----------------------------------------------------------------------------
     def _compact(self, imgs, depth_map) -> bool:
@@ -223,18 +246,25 @@ class CaptionTrainer:
 
     def encode(self, imgs: torch.Tensor, depth_map: torch.Tensor, train: bool):
         compact = self._compact(imgs, depth_map)
-        feats = self.resnet.forward(imgs, train_bn=train, compact=compact)                  # depth_train.py:179
+        feats = self._resnet_eager(imgs, train, compact)                                    # depth_train.py:179
         fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), train,
                                                    workspace=self.enc_ws, compact=compact)   # :204-206
         self.enc_ws = dtape.workspace
+        self.depth_fwd_count += int(train)
         return feats, fdep, dtape
 
     def train_step(self, imgs: torch.Tensor, depth_map: torch.Tensor, captions: torch.Tensor, lengths: Sequence[int],
                    drop_mult: Optional[torch.Tensor] = None, gumbel_u: Optional[torch.Tensor] = None,
                    temp: float = 1.0, precomputed_features: Optional[torch.Tensor] = None,
-                   next_imgs: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   next_imgs: Optional[torch.Tensor] = None, global_tokens: Optional[int] = None,
+                   apply_update: bool = True, virtual_world: Optional[int] = None) -> torch.Tensor:
         """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync).
-        next_imgs: images of the following batch; their (frozen) ResNet forward is overlapped with this step."""
+        next_imgs: images of the following batch; their (frozen) ResNet forward is overlapped with this step.
+        global_tokens: packed tokens (sum of lengths-1) of the GLOBAL batch when data parallel with variable-length
+          captions; default = this rank's count x world size (exact for equal-length batches such as bench.py's).
+        apply_update=False leaves the (scaled, all-reduced) gradients in self.flat.grad and skips AdamW;
+        virtual_world=N scales the gradients as rank-of-N would without any collective - together they let one process
+          reproduce an N-rank step shard by shard (tests)."""
         B = imgs.shape[0] if imgs is not None else precomputed_features.shape[0]
         tmax = max(lengths) - 1
         self.marks = []
@@ -247,7 +277,7 @@ class CaptionTrainer:
                 self.prefetched = None
                 compact = feats.shape[1] == native.L_COMPACT
             else:
-                feats = self.resnet.forward(imgs, train_bn=True, compact=compact)           # depth_train.py:179
+                feats = self._resnet_eager(imgs, True, compact)                             # depth_train.py:179
             if next_imgs is not None:
                 self.prefetch_features(next_imgs, compact=self._compact(next_imgs, depth_map))
             self._mark("resnet152_fwd")
@@ -260,9 +290,11 @@ class CaptionTrainer:
                                                        workspace=self.enc_ws,
                                                        compact=feats.shape[1] == native.L_COMPACT)
             self.enc_ws = dtape.workspace
+        self.depth_fwd_count += 1
         self._mark("depth_encoder_fwd")
         if drop_mult is None and self.p_drop > 0:
-            drop_mult = native.dropout_mask((B, tmax, native.D_HID), self.p_drop, self.seed, self.rng_offset, self.device)
+            drop_mult = native.dropout_mask((B, tmax, native.D_HID), self.p_drop, self.drop_seed, self.rng_offset,
+                                            self.device)
             self.rng_offset += B * tmax * native.D_HID // 4 + 1
         mode = 1 if self.hard else 0
         logits, alphas, tape = native.decoder_forward(self.dec_w, feats, fdep, captions, lengths, drop_mult, mode=mode,
@@ -270,8 +302,11 @@ class CaptionTrainer:
         self.dec_ws = tape.workspace
         self._mark("decoder_fwd")
         targets = native.pack_targets(captions, lengths)                                     # :210-213
+        nworld = virtual_world if virtual_world is not None else self.world
+        n_local = int(targets.shape[0])
+        ce_scale = 1.0 / nworld if global_tokens is None else n_local / float(global_tokens)
         loss, dlogits, dalphas = native.caption_loss(logits, targets, None if self.hard else alphas, self.lam,
-                                                     grad_scale=1.0 / self.world,
+                                                     grad_scale=ce_scale, reg_grad_scale=1.0 / nworld,
                                                      in_place=not self.keep_outputs)         # :214-216
         self._mark("loss")
         _, dfeat = native.decoder_backward(tape, dlogits, dalphas, grads=self.dec_g)         # :219
@@ -282,26 +317,59 @@ class CaptionTrainer:
         else:
             native.depth_encoder_backward(dtape, dfeat, grads=self.enc_g)
         self._mark("depth_encoder_bwd+allreduce")
-        self.step_count += 1
-        native.adamw_step(self.flat.data, self.flat.grad, self.flat.exp_avg, self.flat.exp_avg_sq, self.step_count,
-                          lr=self.lr)                                                        # :221
+        if apply_update:
+            self.apply_update()
         self._mark("adamw")
         self.last = {"logits": logits, "alphas": alphas, "features": feats, "depth_features": fdep}
         return loss
 
+    def apply_update(self) -> None:
+        """AdamW on the flat buffer with whatever self.flat.grad holds (depth_train.py:221)."""
+        self.step_count += 1
+        native.adamw_step(self.flat.data, self.flat.grad, self.flat.exp_avg, self.flat.exp_avg_sq, self.step_count,
+                          lr=self.lr)
+
     @torch.no_grad()
-    def eval_loss(self, imgs, depth_map, captions, lengths) -> torch.Tensor:
-        """Validation forward (depth_train.py:248-292): eval-mode BN in both encoders, dropout off."""
+    def eval_loss(self, imgs, depth_map, captions, lengths, gumbel_u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Validation forward: eval-mode BN in both encoders, dropout off.
+        soft (depth_train.py:248-292): CE + attention regulariser;
+        hard (depth_train.py:555-610): decoder.eval_forward = Gumbel-max one-hot attention (mode 2, `gumbel_u`
+        [Tmax,B,196] uniform draws; drawn from torch's CPU generator like attention.py:40 when omitted), CE only."""
         feats, fdep, _ = self.encode(imgs, depth_map, train=False)
-        logits, alphas, tape = native.decoder_forward(self.dec_w, feats, fdep, captions, lengths, None,
-                                                      workspace=self.dec_ws)
+        if self.hard:
+            if gumbel_u is None:
+                gumbel_u = torch.rand(max(lengths) - 1, len(lengths), native.L_CELLS).clamp_(1e-6, 1 - 1e-6).to(self.device)
+            logits, alphas, tape = native.decoder_forward(self.dec_w, feats, fdep, captions, lengths, None, mode=2,
+                                                          gumbel_u=gumbel_u, workspace=self.dec_ws)
+        else:
+            logits, alphas, tape = native.decoder_forward(self.dec_w, feats, fdep, captions, lengths, None,
+                                                          workspace=self.dec_ws)
         self.dec_ws = tape.workspace
-        loss, _, _ = native.caption_loss(logits, native.pack_targets(captions, lengths), alphas, self.lam)
+        loss, _, _ = native.caption_loss(logits, native.pack_targets(captions, lengths),
+                                         None if self.hard else alphas, self.lam)
+        self.last = {"logits": logits, "alphas": alphas, "features": feats, "depth_features": fdep}
         return loss
 
     def state_dicts(self):
-        """Reference-compatible state_dict contents (keys as in SURVEY.md section 8b) for checkpointing."""
+        """state_dict contents of the three reference modules, loadable with strict=True (keys pinned by
+        tests/golden/state_dict_keys.json): Depth_CNN_endoder registers every layer twice (`conv1.*` and
+        `features.0.*`, depth_models.py:19-34 - 42 keys), BatchNorm layers carry `num_batches_tracked` (one increment per
+        train-mode forward: the depth encoder's = optimiser steps taken, the frozen ResNet's = train-mode forwards, Q1)."""
+        dev = self.device
         dec = {k: v.detach().clone() for k, v in self.dec_w.items()}
         enc = {k: v.detach().clone() for k, v in self.enc_w.items()}
         enc.update({k: v.detach().clone() for k, v in self.enc_state.items()})
-        return {"decoder": dec, "depth_encoder": enc, "encoder": {k: v.detach().clone() for k, v in self.rn_w.items()}}
+        nbt = torch.tensor(self.depth_fwd_count, dtype=torch.int64, device=dev)
+        for i, (conv_idx, bn_idx) in zip((1, 2, 3), ((0, 1), (4, 5), (8, 9))):
+            enc[f"bn{i}.num_batches_tracked"] = nbt.clone()
+            for kind in ("weight", "bias"):
+                enc[f"features.{conv_idx}.{kind}"] = enc[f"conv{i}.{kind}"].clone()
+                enc[f"features.{bn_idx}.{kind}"] = enc[f"bn{i}.{kind}"].clone()
+            for kind in ("running_mean", "running_var", "num_batches_tracked"):
+                enc[f"features.{bn_idx}.{kind}"] = enc[f"bn{i}.{kind}"].clone()
+        rgb = {k: v.detach().clone() for k, v in self.rn_w.items()}
+        for k in list(rgb):
+            if k.endswith("running_mean"):
+                rgb[k[:-len("running_mean")] + "num_batches_tracked"] = torch.tensor(self.resnet.train_forwards,
+                                                                                   dtype=torch.int64, device=dev)
+        return {"decoder": dec, "depth_encoder": enc, "encoder": rgb}

@@ -162,7 +162,7 @@ def pack_targets(captions: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor
     lib = _lib.load()
     dec_len = [int(l) - 1 for l in lengths]
     n = sum(batch_sizes_of(dec_len))
-    buf = torch.empty(n + max(dec_len) + 2, dtype=torch.int64, device=captions.device)
+    buf = torch.empty(n + (len(dec_len) + 1) // 2 + 2, dtype=torch.int64, device=captions.device)   # + int32 lengths
     caps = captions if captions.is_contiguous() else captions.contiguous()
     check(lib.dic_pack_targets(ptr(caps), caps.stride(0), _i32_host(dec_len), len(dec_len), ptr(buf), stream_ptr()),
           "dic_pack_targets")
@@ -170,8 +170,10 @@ def pack_targets(captions: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor
 
 
 def caption_loss(logits: torch.Tensor, targets: torch.Tensor, alphas: Optional[torch.Tensor], lam: float = 0.7,
-                 grad_scale: float = 1.0, in_place: bool = False):
-    """dic_caption_loss. Returns (loss [1] device tensor, dlogits, dalphas or None)."""
+                 grad_scale: float = 1.0, in_place: bool = False, reg_grad_scale: Optional[float] = None):
+    """dic_caption_loss. Returns (loss [1] device tensor, dlogits, dalphas or None).
+    grad_scale multiplies dlogits, reg_grad_scale (default: the same value) multiplies dalphas - data parallel passes
+    n_packed_r / sum n_packed and 1 / world (see include/dic.h)."""
     lib = _lib.load()
     n, v = logits.shape
     dev = logits.device
@@ -182,6 +184,7 @@ def caption_loss(logits: torch.Tensor, targets: torch.Tensor, alphas: Optional[t
     dalphas = torch.empty_like(alphas) if alphas is not None else None
     scratch = torch.empty(n + B + 8, dtype=torch.float32, device=dev)
     rc = lib.dic_caption_loss(ptr(logits), ptr(targets), n, v, ptr(alphas), B, T, C.c_float(lam), C.c_float(grad_scale),
+                              C.c_float(grad_scale if reg_grad_scale is None else reg_grad_scale),
                               ptr(loss), ptr(dlogits), ptr(dalphas), ptr(scratch), stream_ptr())
     check(rc, "dic_caption_loss")
     return loss, dlogits, dalphas
@@ -296,6 +299,24 @@ def depth_encoder_backward(tape: DepthTape, d_features: torch.Tensor, grads: Opt
     return grads
 
 
+def depth_encoder_decisions(tape: DepthTape) -> Dict[str, torch.Tensor]:
+    """dic_depth_encoder_inspect: the max-pool arg-max indices and pooled maps of the forward that produced `tape`
+    (NHWC), for the parity tests' decision replay.  Keys: pooled1, argmax1, pooled2, argmax2, relu3."""
+    lib = _lib.load()
+    B, _, H, W = tape.depth.shape
+    out = {}
+    for which, name in ((1, "pooled1"), (2, "argmax1"), (3, "pooled2"), (4, "argmax2"), (5, "relu3")):
+        n = C.c_longlong(0)
+        check(lib.dic_depth_encoder_inspect(ptr(tape.workspace), C.c_size_t(tape.workspace.numel()), B, H, W, which,
+                                            C.c_void_p(0), C.byref(n), stream_ptr()), "dic_depth_encoder_inspect")
+        t = torch.empty(n.value, dtype=torch.float32 if which in (1, 3) else torch.uint8, device=tape.depth.device)
+        check(lib.dic_depth_encoder_inspect(ptr(tape.workspace), C.c_size_t(tape.workspace.numel()), B, H, W, which,
+                                            ptr(t), C.byref(n), stream_ptr()), "dic_depth_encoder_inspect")
+        ch = 128 if which <= 2 else 512 if which <= 4 else 2048
+        out[name] = t.view(B, -1, ch)          # [B, PH*PW, C]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # RGB encoder (dic_resnet_fwd)
 # ---------------------------------------------------------------------------------------------
@@ -359,6 +380,7 @@ class ResNetRunner:
                 tens.append(t)
             self.keep.append(tens)
         self.workspace: Optional[torch.Tensor] = None
+        self.train_forwards = 0          # train-mode forwards so far (BatchNorm num_batches_tracked, quirk Q1)
 
     def forward(self, imgs: torch.Tensor, train_bn: bool, out: Optional[torch.Tensor] = None,
                 compact: bool = False) -> torch.Tensor:
@@ -384,6 +406,8 @@ class ResNetRunner:
         rc = fn(self.table, self.n_layers, self.blocks, ptr(x), B, H, W, 1 if train_bn else 0, self.mode, ptr(out),
                 ptr(self.workspace), C.c_size_t(self.workspace.numel()), stream_ptr())
         check(rc, "dic_resnet_fwd")
+        if train_bn and not torch.cuda.is_current_stream_capturing():
+            self.train_forwards += 1
         return out
 
 

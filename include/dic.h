@@ -131,13 +131,16 @@ int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const floa
  *      + lam * mean_{B,L}((1 - sum_t alpha)^2).  targets: int64 [n_packed] (device, packed like the
  *      logits).  Writes loss[0] (device), dlogits [n_packed,V] (may alias logits) and, if alphas is
  *      non-NULL, dalphas [B,Tmax,196].  alphas NULL -> CE only (hard path, depth_train.py:530).
- *      grad_scale multiplies both gradients (1/world_size for data parallel).
+ *      ce_grad_scale multiplies dlogits and reg_grad_scale multiplies dalphas (the loss value is unscaled).  Single
+ *      device: 1, 1.  Data parallel, rank r of N: n_packed_r / sum_r n_packed_r (token-weighted: the sum over ranks is
+ *      the gradient of the global token mean) and 1/N (equal per-rank batch).  A target outside [0, V) - where
+ *      F.cross_entropy raises - makes the loss NaN.
  *      scratch: >= (n_packed + B + 8) floats. */
 int dic_caption_loss(const float* logits, const int64_t* targets, int n_packed, int V, const float* alphas, int B,
-                     int Tmax, float lam, float grad_scale, float* loss, float* dlogits, float* dalphas,
-                     float* scratch, void* stream);
+                     int Tmax, float lam, float ce_grad_scale, float reg_grad_scale, float* loss, float* dlogits,
+                     float* dalphas, float* scratch, void* stream);
 /* packed targets = pack_padded_sequence(captions[:,1:], lengths-1).data (depth_train.py:210-213);
- * `targets` needs room for n_packed + Tmax int64 (the tail stages two small int tables). */
+ * `targets` needs room for n_packed int64 + B int32 (the tail holds the device copy of dec_lengths). */
 int dic_pack_targets(const int64_t* captions, int cap_stride, const int* dec_lengths, int B, int64_t* targets,
                      void* stream);
 
@@ -183,6 +186,17 @@ int dic_depth_encoder_fwd_map(const dic_depth_encoder_weights* w, const dic_dept
 int dic_depth_encoder_bwd_map(const dic_depth_encoder_weights* w, const float* depth, const float* d_feature_map, int B,
                               int H, int W, const dic_depth_encoder_grads* gr, void* workspace, size_t workspace_bytes,
                               void* stream);
+
+/* Diagnostic aid for the parity tests: the selections the last dic_depth_encoder_fwd* call on `workspace` made.  ReLU and
+ * max-pool are the only discontinuous operations of the path: an element within fp32 rounding of a tie may be selected
+ * differently by two correct fp32 evaluations, which moves gradients by percents; the tests therefore replay the oracle
+ * with THESE selections (and check that they differ from the oracle's own only at such ties).
+ *   which 1: pooled map 1, float [B,P1h,P1w,128] (NHWC; > 0 <=> the ReLU under the pool passed)   2: its arg-max,
+ *   uint8 kh*3+kw inside the 3x3 window;   3 / 4: the same for layer 2, [B,P2h,P2w,512];
+ *   5: the layer-3 ReLU decisions as the backward takes them, uint8 [B,P2h,P2w,2048] (1 = passes).
+ * *n_out (nullable) receives the element count; out == NULL only queries it.  Device-to-device copy on `stream`. */
+int dic_depth_encoder_inspect(const void* workspace, size_t workspace_bytes, int B, int H, int W, int which, void* out,
+                              long long* n_out, void* stream);
 
 /* ---- RGB encoder: CNNEncoder_Atten (Base_caption_model/base_caption_models.py:18-45) = torchvision
  *      ResNet-152 (Bottleneck v1.5; blocks = {3,8,36,3}) minus fc, avgpool -> AdaptiveAvgPool2d(14).

@@ -195,6 +195,66 @@ def depth_encoder_forward(w: Dict[str, Tensor], state: Dict[str, Tensor], depth:
     return x.permute(0, 2, 3, 1).flatten(1, 2)
 
 
+def _windows3(z: Tensor) -> Tensor:
+    """[B,C,H,W] -> the non-overlapping 3x3 windows of max_pool2d(z, 3) as [B,C,PH,PW,9] (index kh*3+kw)."""
+    B, C, H, W = z.shape
+    ph, pw = H // 3, W // 3
+    return z[:, :, :ph * 3, :pw * 3].reshape(B, C, ph, 3, pw, 3).permute(0, 1, 2, 4, 3, 5).reshape(B, C, ph, pw, 9)
+
+
+def depth_encoder_forward_replay(w: Dict[str, Tensor], state: Dict[str, Tensor], depth: Tensor,
+                                 decisions: Dict[str, Tensor]):
+    """Depth_CNN_endoder.forward in train mode (depth_models.py:49-56) with the SELECTIONS of its discontinuous
+    operations given instead of recomputed: `decisions` (from another evaluation of the same network, e.g. the HIP
+    path's dic_depth_encoder_inspect) holds, NHWC-flattened as [B, PH*PW, C]:
+      argmax1/argmax2 (uint8 kh*3+kw: which window element each max-pool output takes),
+      pooled1/pooled2 (float; > 0 <=> the ReLU under the pool passed), relu3 (uint8: the last ReLU passes).
+    ReLU and max-pool are piecewise linear, so with the selections fixed the network is smooth and two fp32 (or fp64)
+    evaluations agree to rounding level; near a tie the selections themselves can legitimately differ.  The report says
+    how far every given selection is from this evaluation's own choice:
+      report[name] = (number of selections differing from this evaluation's own,
+                      worst shortfall = max over them of (own best value - selected value) / max|z|  for arg-max,
+                                                        |value at the ReLU| / max|z|                   for ReLU).
+    A shortfall at fp32 rounding level (<~ 1e-5) means the differing selection is a tie-break, not an error.
+    Works in the dtype of `w` / `depth` (fp64 for the yardstick)."""
+    report = {}
+
+    def stage(x, i, pooled_key, arg_key):
+        z = batch_norm(x, w, f"bn{i}.", True, state)
+        win = _windows3(z)                                                     # [B,C,PH,PW,9]
+        B, C, ph, pw, _ = win.shape
+        idx = decisions[arg_key].reshape(B, ph, pw, C).permute(0, 3, 1, 2).long()
+        passed = (decisions[pooled_key].reshape(B, ph, pw, C).permute(0, 3, 1, 2) > 0)
+        sel = win.gather(4, idx.unsqueeze(-1)).squeeze(-1)
+        scale = float(z.detach().abs().max())
+        with torch.no_grad():
+            best = win.max(dim=4).values
+            own_pass = best > 0
+            # the arg-max only matters where the ReLU passes (a clipped window has zero gradient whatever is picked)
+            differs = (sel < best) & (passed | own_pass)
+            short = float(((best - sel) * differs).max()) / scale if bool(differs.any()) else 0.0
+            rdiff = passed != own_pass
+            rshort = float((best.abs() * rdiff).max()) / scale if bool(rdiff.any()) else 0.0
+            report[f"pool{i}"] = (int(differs.sum()), short)
+            report[f"relu{i}"] = (int(rdiff.sum()), rshort)
+        return sel * passed.to(sel.dtype)
+
+    x = F.conv2d(depth, w["conv1.weight"], w["conv1.bias"], stride=3)
+    x = stage(x, 1, "pooled1", "argmax1")
+    x = F.conv2d(x, w["conv2.weight"], w["conv2.bias"])
+    x = stage(x, 2, "pooled2", "argmax2")
+    x = F.conv2d(x, w["conv3.weight"], w["conv3.bias"])
+    z = batch_norm(x, w, "bn3.", True, state)
+    B, C, ph, pw = z.shape
+    passed = decisions["relu3"].reshape(B, ph, pw, C).permute(0, 3, 1, 2) > 0
+    with torch.no_grad():
+        rdiff = passed != (z > 0)
+        report["relu3"] = (int(rdiff.sum()), float((z.abs() * rdiff).max()) / float(z.abs().max()) if bool(rdiff.any()) else 0.0)
+    x = z * passed.to(z.dtype)
+    x = F.adaptive_avg_pool2d(x, 14)
+    return x.permute(0, 2, 3, 1).flatten(1, 2), report
+
+
 # --------------------------------------------------------------------------
 # RGB encoder: torchvision ResNet-152 (Bottleneck v1.5, layers [3,8,36,3], stride on the 3x3)
 # followed by AdaptiveAvgPool2d(14)  (Base_caption_model/base_caption_models.py:18-45).
@@ -265,11 +325,19 @@ def adamw_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], exp_avg: Dic
 # --------------------------------------------------------------------------
 def train_step_soft(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_state: Dict[str, Tensor],
                     feats_rgb: Tensor, depth_map: Tensor, captions: Tensor, lengths: Sequence[int],
-                    drop_mult: Optional[Tensor]):
-    """Forward + loss + backward.  Returns (loss, packed_logits, alphas, grads_dec, grads_enc)."""
+                    drop_mult: Optional[Tensor], decisions: Optional[Dict[str, Tensor]] = None,
+                    report: Optional[dict] = None):
+    """Forward + loss + backward.  Returns (loss, packed_logits, alphas, grads_dec, grads_enc).
+    decisions: replay the depth encoder's ReLU / max-pool selections (depth_encoder_forward_replay; `report` receives
+    its tie report) instead of taking them afresh - parity tests only."""
     dw = {k: v.detach().clone().requires_grad_(True) for k, v in dec_w.items()}
     ew = {k: v.detach().clone().requires_grad_(True) for k, v in enc_w.items()}
-    fd = depth_encoder_forward(ew, enc_state, depth_map.detach(), train=True)     # :204-206
+    if decisions is None:
+        fd = depth_encoder_forward(ew, enc_state, depth_map.detach(), train=True)     # :204-206
+    else:
+        fd, rep = depth_encoder_forward_replay(ew, enc_state, depth_map.detach(), decisions)
+        if report is not None:
+            report.update(rep)
     packed, bsz, alphas = decoder_forward(dw, feats_rgb, fd, captions, lengths, drop_mult)
     loss = caption_loss(packed, pack_targets(captions, lengths), alphas)          # :210-216
     loss.backward()                                                                # :219

@@ -46,7 +46,9 @@ def test_collate_for_dep_end_to_end(lib):
     w2i = {"a": 0, "man": 1, "rides": 2, "<start>": 3, "<end>": 4, "<unk>": 5, "<null>": 6}
     g = torch.Generator().manual_seed(4)
     batch = [(torch.rand(3, 224, 224, generator=g), [c] * 5) for c in ("a man", "a man rides a man", "a")]
-    imgs, imgs_dep, targets, lengths, allcaps = util.collate_func_for_dep(batch, w2i, device=DEV)
+    raw, raw2, targets, lengths, allcaps = util.collate_func_for_dep(batch, w2i)       # host only: DataLoader workers
+    assert not raw.is_cuda and raw2 is raw and not targets.is_cuda
+    imgs, imgs_dep = util.device_transforms(raw.to(DEV))                              # util.py:100-101 on the GPU
     assert lengths == sorted(lengths, reverse=True) == [7, 4, 3]
     assert imgs.shape == (3, 3, 224, 224) and imgs_dep.shape == (3, 3, 384, 384) and imgs.is_cuda
     assert targets.shape == (3, 7) and int(targets[2, 3]) == w2i["<null>"]

@@ -1,30 +1,86 @@
 """GPU: rehearsal of the N>1 path of bench.py / engine on a ONE-GPU box: two ranks share cuda:0 and exchange
 gradients over gloo (RCCL refuses two ranks on one device).  Everything except the transport is the code the driver
-runs at N=2,4,8: rank≠0 branches, bucketed overlapped exchange with device tensors, lock-stepped extra steps."""
+runs at N=2,4,8: the `python bench.py --gpus N` self-launch, rank != 0 branches, bucketed overlapped exchange with device
+tensors, token-weighted gradient scaling, lock-stepped extra steps."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHARE = dict(DIC_DIST_BACKEND="gloo", DIC_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
-def test_two_rank_bench_over_gloo_on_one_gpu(lib):
+def _json_line(stdout):
+    return json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_gpus2_self_launch_over_gloo_on_one_gpu(lib):
+    """`python bench.py --gpus 2` with NO launcher on the command line must itself start two ranks (the way the driver's
+    N=1 command line would reach N>1) and report them."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SHARE)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-alt-mode"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["global_batch"] == 16
+    assert d["config"]["batch_per_gpu"] == 8 and d["scaling"] == "weak" and "all-reduce" in d["config"]["collective"]
+    assert d["value"] > 0 and d["loss"] == d["loss"]            # finite
+
+
+def test_bench_rejects_world_size_mismatch(lib):
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path):
+    """N-rank == 1-rank: two real ranks (own process each, gloo all-reduce of the two gradient buckets) take one training
+    step on the two halves of a RAGGED length-sorted global batch; a single process then replays the same step shard by
+    shard (virtual_world=2: same per-shard BatchNorm statistics = DDP semantics, same token-weighted gradient scaling),
+    sums the two gradient buffers and applies AdamW.  Post-step parameters must agree to 1e-5 (all-reduce vs in-order sum
+    differ in nothing but the transport), both ranks must hold identical parameters, and the token-weighted mean of the
+    rank losses' CE parts is what a single device would report."""
+    import socket
+    from depth_image_captioning_pub_amd.engine import CaptionTrainer
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_step_worker as wk
+
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, DIC_DIST_BACKEND="gloo", DIC_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SHARE)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["loss"] == d["loss"]            # finite
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_step_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ranks = [torch.load(tmp_path / f"rank{i}.pt") for i in range(2)]
+    assert torch.equal(ranks[0]["params"], ranks[1]["params"]), "ranks diverged after the all-reduced step"
+    assert ranks[0]["drop_seed"] != ranks[1]["drop_seed"], "every rank must draw its own dropout masks"
+    assert ranks[0]["tokens"] > ranks[1]["tokens"]                      # ragged: rank 0 holds the longer captions
+
+    tr = CaptionTrainer(wk.VOCAB, device="cuda:0", seed=7, resnet_layers=(1, 1, 1, 1), conv_mode="bf16x3")
+    gsum, losses = None, []
+    for rank in range(2):
+        imgs, depth, caps, ln, drop, gtok = wk.shard(rank, 2)
+        loss = tr.train_step(imgs.cuda(), depth.cuda(), caps.cuda(), ln, drop_mult=drop.cuda(), global_tokens=gtok,
+                             virtual_world=2, apply_update=False)
+        g = tr.flat.grad.clone()
+        gsum = g if gsum is None else gsum + g
+        losses.append(float(loss.item()))
+    tr.flat.grad.copy_(gsum)
+    tr.apply_update()
+    torch.cuda.synchronize()
+    for rank in range(2):
+        assert abs(ranks[rank]["loss"] - losses[rank]) <= 1e-5, (rank, ranks[rank]["loss"], losses[rank])
+    err = float((tr.flat.data.cpu() - ranks[0]["params"]).abs().max())
+    assert err <= 1e-5, f"2-rank parameters differ from the 1-rank emulation by {err:.3e}"

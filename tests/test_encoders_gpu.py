@@ -71,6 +71,63 @@ def test_depth_encoder_train_fwd_bwd(lib, B, size, seed):
             check_packed(gold, "grad." + k, gk, 5e-3, 2e-3 * float(gk.abs().max()))
 
 
+def _replay_check(w, st, depth, d_out, tie_tol=3e-5, grad_tol=2e-4):
+    """HIP forward/backward of the depth encoder vs an fp64 evaluation of the oracle that REPLAYS the HIP path's ReLU /
+    max-pool selections (dic_depth_encoder_inspect -> orc.depth_encoder_forward_replay).  Returns the tie report."""
+    st_dev = _dev(st)
+    y, tape = native.depth_encoder_forward(_dev(w), st_dev, depth.to(DEV), train=True)
+    grads = native.depth_encoder_backward(tape, d_out.to(DEV))
+    dec = {k: v.cpu() for k, v in native.depth_encoder_decisions(tape).items()}
+    w64 = {k: v.double().clone().requires_grad_(True) for k, v in w.items()}
+    y64, rep = orc.depth_encoder_forward_replay(w64, {k: v.double().clone() for k, v in st.items()}, depth.double(), dec)
+    (y64 * d_out.double()).sum().backward()
+    # 1. every selection that differs from the fp64 evaluation's own choice is a tie-break at fp32 rounding level
+    for name, (count, shortfall) in rep.items():
+        assert shortfall <= tie_tol, f"{name}: {count} selections differ from fp64, worst shortfall {shortfall:.2e} of the map's scale"
+    # 2. with the selections fixed, outputs and all gradients agree with fp64 tightly - no seed is special
+    _close("features", y, y64.detach(), 2e-5)
+    for k in w:
+        if k.startswith("conv") and k.endswith("bias"):       # quirk Q10: exactly zero true gradient; what both sides hold
+            # is the rounding noise of a sum over B*H*W terms - bounded relative to the sibling weight gradient's scale
+            _close("grad." + k, grads[k], w64[k].grad, 0.0, atol=1e-5 * float(w64[k[:-4] + "weight"].grad.abs().max()) + 1e-7)
+        else:
+            _close("grad." + k, grads[k], w64[k].grad, grad_tol)
+    return rep
+
+
+@pytest.mark.parametrize("size", [300, 520])
+def test_depth_encoder_all_seeds_with_fp64_decision_replay(lib, size):
+    """Seeds 52..63 at the sizes where a plain comparison with the fp32 oracle fails for about half of the seeds
+    (gpurun_out/seed_sweep.log of round 1; scripts/diag_depth_encoder_fp64.py shows the failures are symmetric: on some
+    seeds the fp32 ORACLE is the one that sits percents away from fp64).  Cause: ReLU / max-pool selections within fp32
+    rounding of a tie.  With the HIP path's selections replayed in an fp64 evaluation of the oracle, every seed matches at
+    2e-4 of each gradient's scale, and every differing selection is shown to be a tie-break (shortfall <= 3e-5)."""
+    flips = 0
+    for seed in range(52, 64):
+        w, st = syn.depth_encoder_weights(seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        for i in (1, 2, 3):
+            w[f"bn{i}.weight"] = 1.0 + 0.2 * torch.randn(w[f"bn{i}.weight"].shape, generator=g)
+            w[f"bn{i}.bias"] = 0.1 * torch.randn(w[f"bn{i}.bias"].shape, generator=g)
+        depth = syn.depth_maps(1, seed=seed, size=size)
+        d_out = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 7)).standard_normal((1, 196, 2048))
+                                 .astype(np.float32)) * 1e-2
+        rep = _replay_check(w, st, depth, d_out)
+        flips += sum(c for c, _ in rep.values())
+    print(f"size {size}: {flips} tie-break selections differing from fp64 over 12 seeds")
+
+
+@pytest.mark.parametrize("B", [16, 64])
+def test_depth_encoder_bench_shape_with_fp64_decision_replay(lib, B):
+    """Depth-encoder forward + backward at the bench shape (224x224, batch 16 and 64) against the fp64 decision-replay
+    oracle: outputs 2e-5, all 12 gradients 2e-4 of their scale."""
+    w, st = syn.depth_encoder_weights(seed=124)
+    depth = syn.depth_maps(B, seed=123)
+    d_out = torch.from_numpy(np.random.Generator(np.random.PCG64(131)).standard_normal((B, 196, 2048))
+                             .astype(np.float32)) * 1e-2
+    _replay_check(w, st, depth, d_out)
+
+
 def test_depth_encoder_wide_map_uses_generic_layer1(lib):
     """Maps wider than the 640-float rows the packed-FMA layer-1 kernels stage in LDS fall back to the generic gather
     kernels (same results, same API): 52 x 700 map, non-square feature grid pooled to 14 x 14."""

@@ -118,6 +118,115 @@ def test_data_parallel_gradient_decomposition(lib):
     _close("dfeat", torch.cat([df0, df1]) * 2.0, df_full * 2.0, 1e-4)
 
 
+def test_data_parallel_token_weighted_decomposition_ragged(lib):
+    """Variable-length captions: ranks take contiguous slices of the length-sorted batch, so rank 0 holds
+    more packed tokens.  With the cross-entropy gradient of rank r scaled by N_r / sum N and the regulariser's by 1/world
+    (engine.train_step, include/dic.h) the SUM over ranks equals the single-device gradient of
+    CE(mean over all packed tokens) + lam * mean_{B,L}(...) on the whole batch.  Decoder only (no BatchNorm)."""
+    vocab, lengths = 90, [12, 11, 9, 9, 7, 5, 4, 3]
+    B = len(lengths)
+    w = {k: v.to(DEV) for k, v in syn.decoder_weights(vocab, seed=64).items()}
+    f_rgb, f_dep = syn.features(B, 65).to(DEV), syn.features(B, 66, scale=0.5).to(DEV)
+    caps, lens = syn.captions_ragged(lengths, vocab, seed=64)
+    caps = caps.to(DEV)
+    drop = syn.dropout_multiplier(B, max(lens) - 1, 0.5, seed=64).to(DEV)
+    total = sum(l - 1 for l in lens)
+
+    def grads_of(rows, ce_scale, reg_scale):
+        ln = lens[rows]
+        tmax = max(ln) - 1
+        logits, alphas, tape = native.decoder_forward(w, f_rgb[rows], f_dep[rows], caps[rows, : tmax + 1].contiguous(), ln,
+                                                      drop[rows, :tmax].contiguous())
+        tg = native.pack_targets(caps[rows, : tmax + 1].contiguous(), ln)
+        loss, dl, da = native.caption_loss(logits, tg, alphas, grad_scale=ce_scale, reg_grad_scale=reg_scale)
+        g, dfeat = native.decoder_backward(tape, dl, da)
+        return {k: v.clone() for k, v in g.items()}, dfeat.clone()
+
+    g_full, df_full = grads_of(slice(0, B), 1.0, 1.0)
+    n0 = sum(l - 1 for l in lens[: B // 2])
+    g0, df0 = grads_of(slice(0, B // 2), n0 / total, 0.5)
+    g1, df1 = grads_of(slice(B // 2, B), (total - n0) / total, 0.5)
+    assert n0 > total - n0
+    for k in g_full:
+        _close("dp." + k, g0[k] + g1[k], g_full[k], 1e-4, 1e-8)
+    _close("dfeat", torch.cat([df0, df1]), df_full, 1e-4)
+    # equal weights (1/world on both terms) would NOT reproduce the single-device gradient here
+    gw0, _ = grads_of(slice(0, B // 2), 0.5, 0.5)
+    gw1, _ = grads_of(slice(B // 2, B), 0.5, 0.5)
+    k = "linear.weight"
+    assert float((gw0[k] + gw1[k] - g_full[k]).abs().max()) > 1e-3 * float(g_full[k].abs().max())
+
+
+def test_prefetch_is_ordered_with_eager_forwards(lib):
+    """train_step(next_imgs=X) leaves a ResNet forward running on the side stream; eval_loss / a train_step on another
+    batch then run an EAGER forward on the main stream through the same workspace and BatchNorm buffers.  The engine must
+    order the two, and must not replay a graph captured for a workspace that an eager forward of a larger batch has since
+    re-allocated.  Train-mode results do not depend on the running statistics, so every training loss and the final
+    parameters must equal a trainer that never overlaps; the validation loss is taken at a point where both trainers have
+    seen the same batches in the same order (prefetching advances the running statistics of the NEXT batch early, which
+    is the one semantic difference of the software pipelining)."""
+    vocab = 60
+    xs = [syn.rgb_images(4, seed=90 + i, size=64).to(DEV) for i in range(3)]
+    big = syn.rgb_images(6, seed=95, size=64).to(DEV)
+    depth = syn.depth_maps(4, seed=90, size=64).to(DEV)
+    depth6 = syn.depth_maps(6, seed=95, size=64).to(DEV)
+    caps, lens = syn.captions_fixed(4, vocab, 6, seed=90)
+    caps6, lens6 = syn.captions_fixed(6, vocab, 6, seed=95)
+    caps, caps6 = caps.to(DEV), caps6.to(DEV)
+    drop = syn.dropout_multiplier(4, 6, 0.5, seed=90).to(DEV)
+
+    def run(overlap):
+        tr = CaptionTrainer(vocab, device=DEV, resnet_layers=TINY, seed=11, conv_mode="bf16x3")
+        nxt = (lambda i: {"next_imgs": xs[i]}) if overlap else (lambda i: {})
+        out = [tr.train_step(xs[0], depth, caps, lens, drop_mult=drop, **nxt(1)),
+               tr.train_step(xs[1], depth, caps, lens, drop_mult=drop),                 # consumes the prefetch
+               tr.eval_loss(big, depth6, caps6, lens6),     # eager, larger batch: re-allocates the ResNet workspace
+               tr.train_step(xs[2], depth, caps, lens, drop_mult=drop, **nxt(0)),       # prefetch: stale graphs must go
+               tr.train_step(xs[1], depth, caps, lens, drop_mult=drop),     # NOT the prefetched batch: eager while pending
+               tr.train_step(xs[0], depth, caps, lens, drop_mult=drop, **nxt(2)),       # consumes; prefetches again
+               tr.train_step(xs[2], depth, caps, lens, drop_mult=drop)]
+        torch.cuda.synchronize()
+        return [float(x.item()) for x in out], tr.flat.data.clone()
+
+    l_o, p_o = run(True)
+    l_s, p_s = run(False)
+    assert l_o == l_s, (l_o, l_s)
+    assert torch.equal(p_o, p_s)
+
+
+def test_trainer_checkpoint_round_trips_into_the_modules(lib):
+    """CaptionTrainer.state_dicts() must carry the reference's full key sets (tests/golden/state_dict_keys.json, captured
+    from the imported reference classes) and load with strict=True into the shim modules."""
+    import json
+    import os
+    from depth_image_captioning_pub_amd.Captioning_models.Base_caption_model.base_caption_models import CNNEncoder_Atten
+    from depth_image_captioning_pub_amd.Captioning_models.Depth_caption_model.depth_models import (
+        CD_RNNDecoderWithSoftAttention, Depth_CNN_endoder)
+    keys = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_keys.json")))
+    tr = CaptionTrainer(77, device=DEV, seed=3)
+    imgs, depth = syn.rgb_images(2, seed=1, size=64).to(DEV), syn.depth_maps(2, seed=1, size=64).to(DEV)
+    caps, lens = syn.captions_fixed(2, 77, 5, seed=1)
+    tr.train_step(imgs, depth, caps.to(DEV), lens)
+    tr.train_step(imgs, depth, caps.to(DEV), lens)
+    sd = tr.state_dicts()
+    ref_keys = {"decoder": keys["CD_RNNDecoderWithSoftAttention"]["state_dict"],
+                "depth_encoder": keys["Depth_CNN_endoder"]["state_dict"]}
+    for part, ref in ref_keys.items():
+        assert set(sd[part]) == set(ref), (part, set(sd[part]) ^ set(ref))
+        for k, shape in ref.items():
+            if k.startswith("embed") or k.startswith("linear"):
+                continue                                              # vocabulary-sized
+            assert list(sd[part][k].shape) == list(shape), (part, k)
+    assert int(sd["depth_encoder"]["bn1.num_batches_tracked"]) == 2 == int(sd["depth_encoder"]["features.1.num_batches_tracked"])
+    dec = CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, 77, 0.5)
+    dec.load_state_dict(sd["decoder"], strict=True)
+    denc = Depth_CNN_endoder(14)
+    denc.load_state_dict(sd["depth_encoder"], strict=True)
+    enc = CNNEncoder_Atten(14)
+    enc.load_state_dict(sd["encoder"], strict=True)
+    assert int(sd["encoder"]["backbone.1.num_batches_tracked"]) == 2
+
+
 def test_full_pipeline_step_runs_and_learns(lib):
     """End-to-end fused steps incl. the ResNet forward (tiny stack) decrease the loss on a fixed batch."""
     vocab, B = 200, 6

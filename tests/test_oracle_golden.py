@@ -156,3 +156,27 @@ def test_resnet_oracle_shapes_small():
     assert float(w["backbone.1.running_mean"].abs().sum()) > 0            # Q1: running stats moved
     y2 = orc.resnet152_features(w, x, train_bn=False, layers=layers)
     assert y2.shape == (2, 196, 2048) and torch.isfinite(y4).all()
+
+
+def test_depth_encoder_replay_with_own_selections_is_identity():
+    """orc.depth_encoder_forward_replay (used by the GPU parity tests to take ReLU / max-pool tie-breaks out of the
+    comparison) reproduces orc.depth_encoder_forward bit-for-bit when it is handed the selections of that forward."""
+    import torch.nn.functional as F
+    w, st = syn.depth_encoder_weights(seed=3)
+    d = syn.depth_maps(2, seed=3, size=100)
+    fresh = lambda: {k: v.clone() for k, v in st.items()}          # noqa: E731
+    y = orc.depth_encoder_forward(w, fresh(), d, True)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, t.shape[1])     # noqa: E731
+    dec, x = {}, F.conv2d(d, w["conv1.weight"], w["conv1.bias"], stride=3)
+    for i, nxt in ((1, "conv2"), (2, "conv3")):
+        z = orc.batch_norm(x, w, f"bn{i}.", True, fresh())
+        p, a = orc._windows3(torch.relu(z)).max(4)
+        dec[f"pooled{i}"], dec[f"argmax{i}"] = nhwc(p), nhwc(a).to(torch.uint8)
+        x = F.conv2d(p, w[nxt + ".weight"], w[nxt + ".bias"])
+    dec["relu3"] = nhwc((orc.batch_norm(x, w, "bn3.", True, fresh()) > 0).to(torch.uint8))
+    y2, rep = orc.depth_encoder_forward_replay(w, fresh(), d, dec)
+    assert torch.equal(y, y2) and all(c == 0 for c, _ in rep.values())
+    # a flipped selection is reported with its shortfall
+    dec["relu3"][0, 0, 0] ^= 1
+    _, rep = orc.depth_encoder_forward_replay(w, fresh(), d, dec)
+    assert rep["relu3"][0] == 1 and rep["relu3"][1] > 0
