@@ -834,6 +834,89 @@ __global__ void __launch_bounds__(256) dF_init_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward of the stand-alone attention module (autograd of Soft_Attention.forward / Hard_Attention.forward,
+// attention.py:81-95, 132-148): one workgroup per batch row.  Not on the training hot path (the decoders fuse their
+// attention into the step kernels); written for clarity, every reduction in a fixed order.
+//   d alpha_l  = dalpha_l + F_l . dctx              ctx = sum_l alpha_l F_l
+//   d e_l      = alpha_l (d alpha_l - sum_j alpha_j d alpha_j) / temp
+//   d pre[l,a] = d e_l w[a] [P[l,a] + q[a] > 0]     e_l = w . relu(P_l + q) + b,  q = W_h h + b_h
+//   outputs: dP [L,A] (-> dW_z, db_z, dF += dP W_z by GEMMs), dq [A], per-row partials of dw / db, dF_l = alpha_l dctx
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attention_bwd_kernel(
+    const float* __restrict__ F, const float* __restrict__ P, const float* __restrict__ h, const float* __restrict__ W_h,
+    const float* __restrict__ b_h, const float* __restrict__ w_full, const float* __restrict__ alpha,
+    const float* __restrict__ dctx, const float* __restrict__ dalpha, float inv_temp, float* __restrict__ dP,
+    float* __restrict__ dq, float* __restrict__ dwf_part, float* __restrict__ dbf_part, float* __restrict__ dF) {
+  __shared__ __align__(16) float dctx_s[kD];
+  __shared__ float q_s[kA], h_s[kH], da_s[kL], de_s[kL], red_s[4];
+  __shared__ float acc_s[2][2][kA];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int d = tid; d < kD; d += 256) dctx_s[d] = dctx[(long long)b * kD + d];
+  if (tid < kH) h_s[tid] = h[(long long)b * kH + tid];
+  __syncthreads();
+  if (tid < kA) {
+    float q = b_h[tid];
+    for (int k = 0; k < kH; ++k) q += W_h[tid * kH + k] * h_s[k];
+    q_s[tid] = q;
+  }
+  const float* Fb = F + (long long)b * kL * kD;
+  for (int l = w; l < kL; l += 4) {            // d alpha: one wave per cell, lanes stride the 2048 channels
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kD / 256; ++j) {
+      const float4 f = *reinterpret_cast<const float4*>(Fb + (long long)l * kD + j * 256 + lane * 4);
+      const float4 g = *reinterpret_cast<const float4*>(&dctx_s[j * 256 + lane * 4]);
+      s += f.x * g.x + f.y * g.y + f.z * g.z + f.w * g.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) da_s[l] = s + (dalpha ? dalpha[(long long)b * kL + l] : 0.f);
+  }
+  __syncthreads();
+  float al = 0.f, da = 0.f;
+  if (tid < kL) { al = alpha[(long long)b * kL + tid]; da = da_s[tid]; }
+  const float part = wave_sum(al * da);
+  if (lane == 0) red_s[w] = part;
+  __syncthreads();
+  const float dot = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+  if (tid < kL) de_s[tid] = al * (da - dot) * inv_temp;
+  __syncthreads();
+  {  // score backward: thread (half, a) walks half of the cells
+    const int a = tid & (kA - 1), half = tid >> 7;
+    const float qa = q_s[a], wa = w_full[a];
+    float sq = 0.f, sw = 0.f;
+    for (int l = half * (kL / 2); l < (half + 1) * (kL / 2); ++l) {
+      const long long o = ((long long)b * kL + l) * kA + a;
+      const float r = P[o] + qa, de = de_s[l];
+      const float dp = r > 0.f ? de * wa : 0.f;
+      dP[o] = dp;
+      sq += dp;
+      sw += de * fmaxf(r, 0.f);
+    }
+    acc_s[half][0][a] = sq;
+    acc_s[half][1][a] = sw;
+  }
+  __syncthreads();
+  if (tid < kA) {
+    dq[(long long)b * kA + tid] = acc_s[0][0][tid] + acc_s[1][0][tid];
+    dwf_part[(long long)b * kA + tid] = acc_s[0][1][tid] + acc_s[1][1][tid];
+  }
+  if (tid == 0) {
+    float s = 0.f;
+    for (int l = 0; l < kL; ++l) s += de_s[l];
+    dbf_part[b] = s;
+  }
+  float* dFb = dF + (long long)b * kL * kD;     // dF_l = alpha_l * dctx   (the W_z^T dP term is accumulated by a GEMM)
+  for (int l = 0; l < kL; ++l) {
+    const float a_l = alpha[(long long)b * kL + l];
+#pragma unroll
+    for (int j = 0; j < kD / 1024; ++j) {
+      const float4 g = *reinterpret_cast<const float4*>(&dctx_s[j * 1024 + tid * 4]);
+      *reinterpret_cast<float4*>(dFb + (long long)l * kD + j * 1024 + tid * 4) = make_float4(a_l * g.x, a_l * g.y, a_l * g.z, a_l * g.w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // greedy decoding helpers (batch_sample / sample, depth_models.py:216-305): everything stays on the device
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fill_ids_kernel(long long* ids, int n, long long v) {
@@ -1329,6 +1412,57 @@ int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const floa
                      (const float*)nullptr, 0, 1, mode, gumbel_u, B, temp, alpha, (float*)nullptr, ctx,
                      (float*)nullptr, (float*)nullptr, 0, FusedLstm{});
   DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+size_t dic_attention_bwd_workspace_bytes(int B) {
+  Carver c(nullptr, 0);
+  c.take<float>((size_t)B * kL * kA); c.take<float>((size_t)B * kL * kA);     // P, dP
+  c.take<float>((size_t)B * kA); c.take<float>((size_t)B * kA); c.take<float>((size_t)B);   // dq, dw partials, db partials
+  c.take<float>((size_t)kA * kD);                                            // W_z^T
+  c.take<float>((size_t)64 * kA);                                            // column-sum scratch
+  return c.off;
+}
+
+int dic_attention_bwd(const float* enc_att_w, const float* enc_att_b, const float* dec_att_w, const float* dec_att_b,
+                      const float* full_att_w, const float* feats, const float* h, const float* alpha, int B, int mode,
+                      float temp, const float* d_ctx, const float* d_alpha, float* g_enc_att_w, float* g_enc_att_b,
+                      float* g_dec_att_w, float* g_dec_att_b, float* g_full_att_w, float* g_full_att_b, float* d_feats,
+                      float* d_h, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DIC_REQUIRE(enc_att_w && enc_att_b && dec_att_w && dec_att_b && full_att_w && feats && h && alpha && d_ctx &&
+                  g_enc_att_w && g_enc_att_b && g_dec_att_w && g_dec_att_b && g_full_att_w && g_full_att_b && d_feats &&
+                  d_h && workspace && B > 0, "attention_bwd: bad arguments");
+  DIC_REQUIRE(mode == 0 || mode == 1, "attention_bwd: only soft (0) and Gumbel-softmax (1) attention are differentiable");
+  DIC_REQUIRE(workspace_bytes >= dic_attention_bwd_workspace_bytes(B), "attention_bwd: workspace too small");
+  Carver c(workspace, workspace_bytes);
+  float* P = c.take<float>((size_t)B * kL * kA);
+  float* dP = c.take<float>((size_t)B * kL * kA);
+  float* dq = c.take<float>((size_t)B * kA);
+  float* dwp = c.take<float>((size_t)B * kA);
+  float* dbp = c.take<float>((size_t)B);
+  float* WzT = c.take<float>((size_t)kA * kD);
+  float* cs = c.take<float>((size_t)64 * kA);
+  DIC_TRY(gemm(B * kL, kA, kD, op_rowk(feats, kD), op_rowk(enc_att_w, kD), ep_store(P, kA, enc_att_b), st));
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B), dim3(256), 0, st, feats, (const float*)P, h, dec_att_w, dec_att_b,
+                     full_att_w, alpha, d_ctx, d_alpha, mode == 1 ? 1.0f / temp : 1.0f, dP, dq, dwp, dbp, d_feats);
+  DIC_LAUNCH_CHECK();
+  // encoder_att: dW_z = dP^T F, db_z = colsum(dP), dF += dP W_z
+  DIC_TRY(gemm(kA, kD, B * kL, op_colk(dP, kA), op_colk(feats, kD), ep_store(g_enc_att_w, kD), st));
+  DIC_TRY(colsum(dP, kA, B * kL, kA, g_enc_att_b, cs, st));
+  DIC_TRY(launch_transpose(enc_att_w, WzT, kA, kD, st));
+  {
+    GemmEpilogue ep = ep_store(d_feats, kD);
+    ep.accumulate = 1;
+    DIC_TRY(gemm(B * kL, kD, kA, op_rowk(dP, kA), op_rowk(WzT, kA), ep, st));
+  }
+  // decoder_att: dW_h = dq^T h, db_h = colsum(dq), dh = dq W_h
+  DIC_TRY(gemm(kA, kH, B, op_colk(dq, kA), op_colk(h, kH), ep_store(g_dec_att_w, kH), st));
+  DIC_TRY(colsum(dq, kA, B, kA, g_dec_att_b, cs, st));
+  DIC_TRY(gemm(B, kH, kA, op_rowk(dq, kA), op_colk(dec_att_w, kH), ep_store(d_h, kH), st));
+  // full_att
+  DIC_TRY(colsum(dwp, kA, B, kA, g_full_att_w, cs, st));
+  DIC_TRY(colsum(dbp, 1, B, 1, g_full_att_b, cs, st));
   return DIC_OK;
 }
 

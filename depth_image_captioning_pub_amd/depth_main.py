@@ -12,6 +12,9 @@ import torch
 from .Captioning_models.Depth_caption_model.depth_train import train_Cdepth_hard, train_Cdepth_soft
 
 
+EXP_TIME = 3                                   # depth_main.py:16: every experiment is repeated three times
+
+
 def torch_seed(seed=123):                      # depth_main.py:7-12
     torch.manual_seed(seed)
     if torch.cuda.is_available():
@@ -21,7 +24,7 @@ def torch_seed(seed=123):                      # depth_main.py:7-12
 
 def main(argv=None):
     torch_seed()
-    exp_time = 3
+    exp_time = EXP_TIME
     datas = ["coco", "original", "synthetic"]
     args = list(sys.argv if argv is None else argv)
     if len(args) < 4:

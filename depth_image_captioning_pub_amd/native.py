@@ -456,3 +456,24 @@ def attention_forward(att: Dict[str, torch.Tensor], feats: torch.Tensor, h: torc
                                C.c_size_t(ws.numel()), stream_ptr())
     check(rc, "dic_attention_fwd")
     return ctx, alpha
+
+
+def attention_backward(att: Dict[str, torch.Tensor], feats: torch.Tensor, h: torch.Tensor, alpha: torch.Tensor,
+                       d_ctx: torch.Tensor, d_alpha: Optional[torch.Tensor], mode: int = 0, temp: float = 1.0):
+    """dic_attention_bwd. Returns (grads dict keyed like `att`, d_feats [B,196,2048], d_h [B,128])."""
+    lib = _lib.load()
+    f, hh, al, dc = _dev_f32(feats, "encoder_out"), _dev_f32(h, "decoder_hidden"), _dev_f32(alpha, "alpha"), _dev_f32(d_ctx, "d_ctx")
+    da = _dev_f32(d_alpha, "d_alpha") if d_alpha is not None else None
+    B = f.shape[0]
+    t = {k: _dev_f32(v, k) for k, v in att.items()}
+    g = {k: torch.empty_like(v) for k, v in t.items()}
+    lib.dic_attention_bwd_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(lib.dic_attention_bwd_workspace_bytes(B), dtype=torch.uint8, device=f.device)
+    d_feats, d_h = torch.empty_like(f), torch.empty_like(hh)
+    rc = lib.dic_attention_bwd(ptr(t["encoder_att.weight"]), ptr(t["encoder_att.bias"]), ptr(t["decoder_att.weight"]),
+                               ptr(t["decoder_att.bias"]), ptr(t["full_att.weight"]), ptr(f), ptr(hh), ptr(al), B, mode,
+                               C.c_float(temp), ptr(dc), ptr(da), ptr(g["encoder_att.weight"]), ptr(g["encoder_att.bias"]),
+                               ptr(g["decoder_att.weight"]), ptr(g["decoder_att.bias"]), ptr(g["full_att.weight"]),
+                               ptr(g["full_att.bias"]), ptr(d_feats), ptr(d_h), ptr(ws), C.c_size_t(ws.numel()), stream_ptr())
+    check(rc, "dic_attention_bwd")
+    return g, d_feats, d_h

@@ -120,12 +120,22 @@ int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rg
 
 /* stand-alone attention module: Soft_Attention.forward (attention.py:81-95), Hard_Attention.forward (:132-148,
  *   mode 1, gumbel_u [B,196], temp) and Hard_Attention.Hard_sample (:150-167, mode 2): feats [B,196,2048],
- *   h [B,128] -> ctx [B,2048], alpha [B,196] (float; one-hot in mode 2). Forward only. */
+ *   h [B,128] -> ctx [B,2048], alpha [B,196] (float; one-hot in mode 2). */
 size_t dic_attention_workspace_bytes(int B);
 int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const float* dec_att_w, const float* dec_att_b,
                       const float* full_att_w, const float* full_att_b, const float* feats, const float* h, int B,
                       int mode, const float* gumbel_u, float temp, float* ctx, float* alpha, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* autograd backward of the call above (the reference modules are ordinary autograd modules): modes 0 and 1; given
+ *   d_ctx [B,2048] and d_alpha [B,196] (nullable) and the forward's alpha, writes the six parameter gradients, d_feats
+ *   [B,196,2048] and d_h [B,128]. */
+size_t dic_attention_bwd_workspace_bytes(int B);
+int dic_attention_bwd(const float* enc_att_w, const float* enc_att_b, const float* dec_att_w, const float* dec_att_b,
+                      const float* full_att_w, const float* feats, const float* h, const float* alpha, int B, int mode,
+                      float temp, const float* d_ctx, const float* d_alpha, float* g_enc_att_w, float* g_enc_att_b,
+                      float* g_dec_att_w, float* g_dec_att_b, float* g_full_att_w, float* g_full_att_b, float* d_feats,
+                      float* d_h, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- loss of train_Cdepth_soft (depth_train.py:210-216): mean CE over packed tokens
  *      + lam * mean_{B,L}((1 - sum_t alpha)^2).  targets: int64 [n_packed] (device, packed like the

@@ -31,3 +31,15 @@ def test_collate_sorting_and_padding(monkeypatch):
     assert targets[2].tolist() == [7, 0, 1, 8] + [10] * 6                 # padded with <null>
     with pytest.raises(Exception):
         util.norm_trans(torch.zeros(1, 3, 4, 4))                           # GPU only: no CPU fallback
+
+
+def test_collate_functions_are_host_only():
+    """The reference hands these to a DataLoader with num_workers=4 (depth_train.py:93): they must run in a process that
+    cannot touch the GPU and return CPU tensors; the image transforms of util.py:100-101 happen on the device later."""
+    random.seed(1)
+    batch = [(torch.rand(3, 8, 8), [c] * 5) for c in ("a man", "a man rides a horse", "a")]
+    imgs, targets, lengths = util.collate_func(batch, W2I)
+    assert not imgs.is_cuda and imgs.shape == (3, 3, 8, 8) and lengths == [7, 4, 3]
+    raw, raw_dep, targets, lengths, allcaps = util.collate_func_for_dep(batch, W2I)
+    assert raw is raw_dep and not raw.is_cuda and targets.dtype == torch.int64 and lengths == [7, 4, 3]
+    assert float(raw.min()) >= 0.0 and allcaps[0].startswith("a man rides")        # un-normalised, sorted with the batch

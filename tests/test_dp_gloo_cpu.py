@@ -81,3 +81,20 @@ def test_flat_params_are_aligned_views():
 def test_shard_rows_rejects_uneven_batches():
     with pytest.raises(Exception, match="divisible"):
         shard_rows(10, 4, 0)
+
+
+def test_bench_rejects_world_size_mismatch():
+    """`--gpus N` must describe the job that is actually running (`--gpus 8` used to run one GPU and report
+    n_gpus 1).  The check happens before any GPU is touched, so it runs here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+    # and without a launcher, asking for more GPUs than are visible fails loudly instead of benchmarking fewer
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DIC_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)

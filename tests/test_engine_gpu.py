@@ -24,6 +24,17 @@ def _close(name, got, ref, tol, atol=0.0):
 
 
 def test_three_fused_steps_vs_oracle(lib):
+    """Three optimiser steps (depth encoder fwd/bwd + decoder fwd/bwd + AdamW with carried moments) against the oracle.
+    Every step starts from the ORACLE's state (weights, Adam moments, step count, BatchNorm running statistics copied into
+    the trainer), so each of the three comparisons is tight instead of inheriting the previous steps' drift, and the
+    oracle replays the HIP path's ReLU / max-pool selections (tests/test_encoders_gpu.py: they differ only at ties).
+    Per step: loss 1e-5, argmax identical, every gradient 1e-3 of its scale, and the post-step weights:
+      * elements whose update is well conditioned, |m_hat| / (sqrt(v_hat) + eps) computed from gradients with
+        |g| > 1e-5 at this and all earlier steps: |dw| <= 2e-6 + 1e-5 * max|w|  (lr = 1e-3, so 1e-2 of one update);
+      * every element: |dw| <= 2.2e-3 (two updates of size lr - AdamW divides by sqrt(v) + 1e-8, so where |g| is below
+        the gradient error the update DIRECTION is summation-order noise on both sides);
+      * every element of the Adam moments (linear / quadratic in the gradients, hence well conditioned everywhere):
+        exp_avg 1e-3 and exp_avg_sq 2e-3 of each tensor's max - the optimiser state is pinned for ALL elements."""
     lengths, vocab = [9, 7, 7, 4, 3], 50
     B = len(lengths)
     dec = syn.decoder_weights(vocab, seed=31)
@@ -38,32 +49,55 @@ def test_three_fused_steps_vs_oracle(lib):
     m = {k: torch.zeros_like(v) for k, v in params.items()}
     v2 = {k: torch.zeros_like(v) for k, v in params.items()}
     st_ref = {k: v.clone() for k, v in st.items()}
+    well = {k: torch.ones_like(v, dtype=torch.bool) for k, v in params.items()}
+    n_ill = n_all = 0
+
+    def view(buf, k):
+        return tr.flat.view(buf, ("decoder." if k[0] == "d" else "depth_encoder.") + k[2:])
+
     for step in (1, 2, 3):
-        dw = {k[2:]: v for k, v in params.items() if k.startswith("d.")}
-        ew = {k[2:]: v for k, v in params.items() if k.startswith("e.")}
-        loss_ref, packed_ref, _, gd, ge = orc.train_step_soft(dw, ew, st_ref, f_rgb, depth, caps, lens, drop)
-        grads = {**{"d." + k: v for k, v in gd.items()}, **{"e." + k: v for k, v in ge.items()}}
-        orc.adamw_step(params, grads, m, v2, step=step)
+        for k in params:                     # synchronise the trainer with the oracle's state before the step
+            view(tr.flat.data, k).copy_(params[k])
+            view(tr.flat.exp_avg, k).copy_(m[k])
+            view(tr.flat.exp_avg_sq, k).copy_(v2[k])
+        for k in st_ref:
+            tr.enc_state[k].copy_(st_ref[k])
+        tr.step_count = step - 1
         loss = tr.train_step(None, depth.to(DEV), caps.to(DEV), lens, drop_mult=drop.to(DEV),
                              precomputed_features=f_rgb.to(DEV))
-        assert abs(float(loss.item()) - float(loss_ref)) <= 1e-4, (step, float(loss.item()), float(loss_ref))
+        torch.cuda.synchronize()
+        sel = {k: v.cpu() for k, v in native.depth_encoder_decisions(
+            native.DepthTape(tr.enc_ws, depth.to(DEV), tr.enc_w, False)).items()}
+        dw = {k[2:]: v for k, v in params.items() if k.startswith("d.")}
+        ew = {k[2:]: v for k, v in params.items() if k.startswith("e.")}
+        rep = {}
+        loss_ref, packed_ref, _, gd, ge = orc.train_step_soft(dw, ew, st_ref, f_rgb, depth, caps, lens, drop, decisions=sel,
+                                                              report=rep)
+        assert all(short <= 3e-5 for _, short in rep.values()), rep
+        grads = {**{"d." + k: v for k, v in gd.items()}, **{"e." + k: v for k, v in ge.items()}}
+        assert abs(float(loss.item()) - float(loss_ref)) <= 1e-5, (step, float(loss.item()), float(loss_ref))
         assert torch.equal(tr.last["logits"].argmax(1).cpu(), packed_ref.argmax(1))
-        # AdamW divides by sqrt(v)+1e-8: where |grad| is near 1e-8 (the exactly-zero-gradient tensors of quirk Q10 and
-        # isolated elements elsewhere) the update DIRECTION is summation-order noise of size <= lr on each side, and
-        # those perturbed weights then feed later steps.  So: after the first (synchronised) step every element
-        # with a well-conditioned gradient (|g| > 1e-5) must match tightly; every element is always within
-        # steps * 2 * lr.
         for k in params:
-            got = (tr.dec_w if k[0] == "d" else tr.enc_w)[k[2:]].detach().cpu().double()
-            err = (got - params[k].double()).abs()
-            assert float(err.max()) <= step * 2.2e-3, f"step {step} {k}: {float(err.max()):.3e}"
-            if step == 1:
-                ok = grads[k].abs() > 1e-5
-                if bool(ok.any()):
-                    assert float(err[ok].max()) <= 2e-6 + 1e-5 * float(params[k].abs().max()), \
-                        f"{k}: {float(err[ok].max()):.3e} on well-conditioned elements"
-    for k in st:      # running statistics follow the (slightly diverged, see above) weights over 3 steps
-        _close(k, tr.enc_state[k], st_ref[k], 1e-2)
+            if k.endswith("full_att.bias") or (k.startswith("e.conv") and k.endswith("bias")):
+                continue                                                     # quirk Q10: zero true gradient
+            _close(f"step {step} grad {k}", view(tr.flat.grad, k), grads[k], 1e-3)
+        orc.adamw_step(params, grads, m, v2, step=step)
+        for k in params:
+            well[k] &= grads[k].abs() > 1e-5
+            err = (view(tr.flat.data, k).detach().cpu().double() - params[k].double()).abs()
+            assert float(err.max()) <= 2.2e-3, f"step {step} {k}: {float(err.max()):.3e}"
+            if bool(well[k].any()):
+                assert float(err[well[k]].max()) <= 2e-6 + 1e-5 * float(params[k].abs().max()), \
+                    f"step {step} {k}: {float(err[well[k]].max()):.3e} on well-conditioned elements"
+            if not (k.endswith("full_att.bias") or (k.startswith("e.conv") and k.endswith("bias"))):
+                _close(f"step {step} exp_avg {k}", view(tr.flat.exp_avg, k), m[k], 1e-3, 1e-12)
+                _close(f"step {step} exp_avg_sq {k}", view(tr.flat.exp_avg_sq, k), v2[k], 2e-3, 1e-20)
+        for k in st_ref:                     # BatchNorm running statistics of the step
+            _close(f"step {step} {k}", tr.enc_state[k], st_ref[k], 1e-4, 1e-7)
+    for k in params:
+        n_ill += int((~well[k]).sum())
+        n_all += well[k].numel()
+    print(f"elements compared at 2.2e-3 only (|g| <= 1e-5 at some step): {n_ill} of {n_all}")
 
 
 def test_decoder_adamw3_golden(lib):

@@ -63,6 +63,82 @@ def test_hard_attention_module_rng_and_onehot(lib):
     _close("ctx", ctx2, c_ref, 1e-4)
 
 
+@pytest.mark.parametrize("hard", [False, True])
+def test_attention_modules_are_differentiable(lib, hard):
+    """Soft_Attention.forward / Hard_Attention.forward are ordinary autograd modules in the reference
+    (attention.py:81-95, 132-148): gradients w.r.t. the six parameters, encoder_out and decoder_hidden vs the oracle's
+    autograd, for a loss that uses both outputs."""
+    w = syn.decoder_weights(50, seed=15)
+    aw = {k[len("attention."):]: v for k, v in w.items() if k.startswith("attention.")}
+    att = (Hard_Attention if hard else Soft_Attention)(2048, 128, 128)
+    att.load_state_dict(aw)
+    att.to(DEV)
+    B = 3
+    rng = np.random.Generator(np.random.PCG64(16))
+    feats = syn.features(B, 17, replicate=False)
+    h = torch.from_numpy(rng.standard_normal((B, 128)).astype(np.float32))
+    gc = torch.from_numpy(rng.standard_normal((B, 2048)).astype(np.float32))
+    ga = torch.from_numpy(rng.standard_normal((B, 196)).astype(np.float32))
+    fd, hd = feats.to(DEV).requires_grad_(True), h.to(DEV).requires_grad_(True)
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    fr, hr = feats.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    if hard:
+        temp = torch.tensor(0.7)
+        torch.manual_seed(79)
+        ctx, alpha = att(fd, hd, DEV, temp)
+        torch.manual_seed(79)
+        c_ref, a_ref = orc.hard_attention_train(wr, fr, hr, torch.rand(B, 196), temp)
+    else:
+        ctx, alpha = att(fd, hd)
+        c_ref, a_ref = orc.soft_attention(wr, fr, hr)
+    ((ctx * gc.to(DEV)).sum() + (alpha * ga.to(DEV)).sum()).backward()
+    ((c_ref * gc).sum() + (a_ref * ga).sum()).backward()
+    _close("ctx", ctx, c_ref, 1e-4)
+    _close("alpha", alpha, a_ref, 1e-4)
+    _close("d encoder_out", fd.grad, fr.grad, 1e-3)
+    _close("d decoder_hidden", hd.grad, hr.grad, 1e-3)
+    for k, p in att.named_parameters():
+        if k == "full_att.bias":
+            _close("grad " + k, p.grad, wr["attention." + k].grad, 0.0, atol=1e-5)      # exactly zero true gradient (Q10)
+        else:
+            _close("grad " + k, p.grad, wr["attention." + k].grad, 1e-3)
+
+
+def test_depth_main_cli_smoke(lib, tmp_path, monkeypatch):
+    """The drop-in CLI of north_star: `depth_main {soft,hard} cnn synthetic` (reference: depth_main.py:14-35 ->
+    train_Cdepth_soft/_hard, depth_train.py:27,338) for a tiny configuration - 1 epoch x 2 iterations, validation
+    (soft: CE + regulariser; hard: eval_forward, CE only), loss CSVs and the three best-validation checkpoints with the
+    reference's file names, which must load back into the drop-in modules with strict=True."""
+    from depth_image_captioning_pub_amd import depth_main
+    from depth_image_captioning_pub_amd.Captioning_models import config as cfg_mod
+    from depth_image_captioning_pub_amd.Captioning_models.Depth_caption_model import depth_train
+
+    class Tiny(cfg_mod.ConfigTrain):
+        def __init__(self):
+            super().__init__()
+            self.batch_size, self.num_epochs, self.vocab_size, self.seq_len, self.iters_per_epoch = 2, 1, 120, 6, 2
+            self.save_directory_Cdep_soft = str(tmp_path / "CNN_depth_soft")
+            self.save_directory_Cdep_hard = str(tmp_path / "CNN_depth_hard")
+    monkeypatch.setattr(depth_train, "ConfigTrain", Tiny)
+    monkeypatch.setattr(depth_main, "EXP_TIME", 1)
+    for kind, tag in (("soft", "depth_soft"), ("hard", "depth_hard")):
+        assert depth_main.main(["depth_main", kind, "cnn", "synthetic"]) == 0
+        d = tmp_path / ("CNN_" + tag)
+        train_csv = (d / f"{tag}_train_loss_synthetic0.csv").read_text().strip().splitlines()
+        val_csv = (d / f"{tag}_val_loss_synthetic0.csv").read_text().strip().splitlines()
+        assert len(train_csv) == 1 and len(val_csv) == 1
+        tl, vl = float(train_csv[0].split(",")[1]), float(val_csv[0].split(",")[1])
+        assert np.isfinite(tl) and np.isfinite(vl) and vl != tl          # a real validation pass, not the train loss
+        enc, ddec, denc = CNNEncoder_Atten(14), None, Depth_CNN_endoder(14)
+        ddec = (CD_RNNDecoderWithHardAttention(128, 128, 2048, 128, 120, DEV, 0.5) if kind == "hard"
+                else CD_RNNDecoderWithSoftAttention(128, 128, 2048, 128, 120, 0.5))
+        enc.load_state_dict(torch.load(d / f"{tag}_encoder_best_synthetic0.pth", weights_only=True), strict=True)
+        ddec.load_state_dict(torch.load(d / f"{tag}_decoder_best_synthetic0.pth", weights_only=True), strict=True)
+        denc.load_state_dict(torch.load(d / f"{tag}_D_encoder_best_synthetic0.pth", weights_only=True), strict=True)
+    assert depth_main.main(["depth_main", "soft", "mlp", "synthetic"]) == 0          # no-op branch of the reference
+    assert depth_main.main(["depth_main", "soft", "cnn", "nonsense"]) == 1
+
+
 def _decoder_case(lengths, vocab, seed):
     B = len(lengths)
     w = syn.decoder_weights(vocab, seed=seed)
