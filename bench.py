@@ -180,6 +180,68 @@ def parity_gate(first, dev: str, conv_mode: str, compact: bool):
                     "and 1e-6-level logits when both sides see the same ResNet features)"}
 
 
+def bench_dpt(args, dev: str, world: int, rank: int):
+    """`--dpt`: images/s of the frozen DPT-Hybrid depth front-end (config 5's extra stage, epoch 0 only): forward at 384x384 +
+    per-image standardisation + resize to 224x224, inputs resident in HBM; every rank runs its own batch (no collective:
+    the estimator is frozen).  Reported beside: achieved exact-fp32 MFMA rate (algorithmic FLOPs / time), the CPU oracle on
+    the host cores (2 images) and the max deviation of one predicted map from it (parity unpinned, see oracle/dpt_oracle.py)."""
+    from depth_image_captioning_pub_amd import synthetic as syn
+    from depth_image_captioning_pub_amd.Captioning_models.Depth_caption_model.DPT_model import DPT_Depthestimator
+    from depth_image_captioning_pub_amd.hostinfo import host_cores
+    B = args.dpt_batch
+    dpt = DPT_Depthestimator(seed=130).to(dev)
+    x = syn.dpt_images(B, seed=123 + rank, size=384).to(dev)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        d = dpt.depth_maps_for_training(x)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d = dpt.depth_maps_for_training(x)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        flops = dpt._runner.flops_per_image(384) * B * args.steps
+        ach = flops / elapsed / 1e12
+        res = {"metric": "images/sec (DPT-Hybrid depth front-end forward, 384x384 -> 224x224 depth maps)",
+               "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"frozen DPT-Hybrid (vitb_rn50_384, 122 M parameters, random init) forward at 384x384, "
+                                      f"batch {B}/GPU, + standardize_depth_map + resize to 224x224 (BASELINE config 5 front-end)",
+                          "batch_per_gpu": B, "parallelism": f"dp{world} (replicas, no collective: frozen)"},
+               "roofline": {"bound": "mfma", "kernel": "whole forward (exact-fp32 MFMA convolutions / linear layers)",
+                            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                            "gflop_per_image": round(dpt._runner.flops_per_image(384) / 1e9, 1)}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import dpt_oracle
+            torch.set_num_threads(host_cores())
+            w = {k[len("model."):]: v.cpu() for k, v in dpt.state_dict().items()}
+            xc = x[:2].cpu()
+            dpt_oracle.depth_front_end(w, xc[:1], dpt.cfg)
+            t1 = time.perf_counter()
+            ref = dpt_oracle.depth_front_end(w, xc, dpt.cfg)
+            tc = time.perf_counter() - t1
+            err = float((d[:2].cpu() - ref).abs().max())
+            res["cpu_baseline"] = {"value": round(2 / tc, 3), "unit": "images/s", "cores": host_cores(), "kind": "port",
+                                   "sample": f"oracle/dpt_oracle.py on 2 images after a 1-image warm-up, {tc:.2f} s"}
+            res["parity"] = {"max_abs_diff_depth_map": err, "images": 2, "range": "[0,1] after standardisation",
+                             "status": "parity unpinned (timm 0.4.12 absent; restated backbone, procedural weights)"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) as a child
     `python -m torch.distributed.run` job BEFORE this process touches a GPU, relay their output, return the exit code."""
@@ -219,6 +281,10 @@ def main():
     ap.add_argument("--reference-cells", action="store_true",
                     help="evaluate the decoder on all 196 annotation cells like the reference (default: the 49 distinct "
                          "cells of the 7x7 encoder maps - identical results, see DESIGN.md 5.3)")
+    ap.add_argument("--dpt", action="store_true",
+                    help="separate workload (never mixed into the headline): forward of the frozen DPT-Hybrid depth "
+                         "front-end of BASELINE config 5 at 384x384 + standardise + resize to 224 (depth_train.py:185-190)")
+    ap.add_argument("--dpt-batch", type=int, default=8)
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
@@ -257,6 +323,8 @@ def main():
     from depth_image_captioning_pub_amd import synthetic as syn
     from depth_image_captioning_pub_amd.engine import CaptionTrainer
 
+    if args.dpt:
+        return bench_dpt(args, dev, world, rank)
     B = args.batch
     trainer = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=args.conv_mode)
     if args.reference_cells:

@@ -33,13 +33,39 @@ def temp_anneal(epoch_num):
     return torch.from_numpy(temp.astype(np.float32)).clone()
 
 
-def _synthetic_batches(config, rank: int, n: int, seed0: int):
+def _synthetic_batches(config, rank: int, n: int, seed0: int, raw: bool = False):
+    """raw=True: un-normalised RGB in [0,1) and no depth map (the DPT front-end predicts it, config 5)."""
     for i in range(n):
         s = seed0 + 7919 * i + rank
-        imgs = syn.rgb_images(config.batch_size, seed=s)
-        depth = syn.depth_maps(config.batch_size, seed=s)
+        imgs = syn.raw_images(config.batch_size, seed=s) if raw else syn.rgb_images(config.batch_size, seed=s)
+        depth = None if raw else syn.depth_maps(config.batch_size, seed=s)
         caps, lens = syn.captions_fixed(config.batch_size, config.vocab_size, config.seq_len, seed=s)
         yield imgs, depth, caps, lens
+
+
+class _DptFrontEnd:
+    """Epoch-0 depth prediction + device-resident cache (depth_train.py:184-202): in epoch 0 the frozen DPT-Hybrid
+    estimator predicts the depth map of every image, which is standardised, resized to 224x224 and stored under its key
+    (the reference keys a CPU dict by the joined caption strings); later epochs fetch whole batches from the cache."""
+
+    def __init__(self, config, capacity: int):
+        from .DPT_model import DPT_Depthestimator
+        from ..util import DepthCache
+        self.dpt = DPT_Depthestimator(getattr(config, "dpt_config", None)).to(config.device)       # :121,126-127 (frozen, eval)
+        self.cache = DepthCache(capacity, device=config.device)
+        self.forwards = self.hits = 0
+
+    def depth_maps(self, epoch: int, keys, raw_gpu: torch.Tensor):
+        from .. import util
+        imgs, imgs_for_dep = util.device_transforms(raw_gpu)                                        # util.py:100-101
+        if epoch == 0:
+            depth = self.dpt.depth_maps_for_training(imgs_for_dep)                                  # :185-190
+            self.cache.put(keys, depth)                                                             # :191-194
+            self.forwards += 1
+        else:
+            depth = self.cache.get(keys)                                                            # :196-202
+            self.hits += 1
+        return imgs, depth
 
 
 def _gumbel_draws(tmax: int, batch: int, epoch: int, iteration: int, rank: int, run: int) -> torch.Tensor:
@@ -48,12 +74,12 @@ def _gumbel_draws(tmax: int, batch: int, epoch: int, iteration: int, rank: int, 
     return syn.gumbel_uniforms(tmax, batch, seed=seed)
 
 
-def _train(ext, useData, hard: bool, config=None, process_group=None):
+def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None):
     config = config or ConfigTrain()
     if useData != "synthetic":
-        raise DicError(f"useData={useData!r}: the MSCOCO / original-dataset loaders, the vocabulary pickle and the DPT "
-                       "depth front-end are outside this build's scope (SURVEY.md 8f) and not available offline; "
-                       "use useData='synthetic'")
+        raise DicError(f"useData={useData!r}: the MSCOCO / original-dataset loaders and the vocabulary pickle are outside "
+                       "this build's scope (SURVEY.md 8f) and not available offline; use useData='synthetic' "
+                       "(config.use_dpt = True adds the DPT depth front-end of BASELINE config 5)")
     save_directory = config.save_directory_Cdep_hard if hard else config.save_directory_Cdep_soft
     os.makedirs(save_directory, exist_ok=True)
     tag = "depth_hard" if hard else "depth_soft"
@@ -66,12 +92,17 @@ def _train(ext, useData, hard: bool, config=None, process_group=None):
     temp = torch.tensor(1.0)
     val_loss_best = float("inf")
     history = []
+    use_dpt = bool(getattr(config, "use_dpt", False))        # BASELINE config 5: depth maps from the DPT front-end
+    front = _DptFrontEnd(config, config.iters_per_epoch * config.batch_size) if use_dpt else None
     for epoch in range(config.num_epochs):
         if hard and epoch % config.temp_sch == 0:                       # depth_train.py:481-483
             temp = temp_anneal(epoch)
         window, losses = deque(), []
+        # with the DPT front-end the "dataset" is the same every epoch (that is what makes the depth cache meaningful)
         for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank, config.iters_per_epoch,
-                                                                          1000 * epoch)):
+                                                                          0 if use_dpt else 1000 * epoch, raw=use_dpt)):
+            if use_dpt:
+                imgs, depth = front.depth_maps(epoch, [f"{it}:{i}" for i in range(len(lens))], imgs.to(dev))
             # the reference draws a fresh torch.rand(bs, 196) per decode step of every iteration (attention.py:17); here
             # the T draws of one iteration come as one [T,B,196] tensor from a stream keyed by (epoch, iteration, rank)
             u = _gumbel_draws(max(lens) - 1, len(lens), epoch, it, rank, int(ext)).to(dev) if hard else None
@@ -102,12 +133,14 @@ def _train(ext, useData, hard: bool, config=None, process_group=None):
                 torch.save(sd["encoder"], f"{save_directory}/{tag}_encoder_best_{useData}{ext}.pth")
                 torch.save(sd["decoder"], f"{save_directory}/{tag}_decoder_best_{useData}{ext}.pth")
                 torch.save(sd["depth_encoder"], f"{save_directory}/{tag}_D_encoder_best_{useData}{ext}.pth")
+    if stats is not None and front is not None:
+        stats.update(dpt_forwards=front.forwards, cache_hits=front.hits, cache_entries=len(front.cache.slot))
     return history
 
 
-def train_Cdepth_soft(ext, useData, config=None, process_group=None):
-    return _train(ext, useData, hard=False, config=config, process_group=process_group)
+def train_Cdepth_soft(ext, useData, config=None, process_group=None, stats=None):
+    return _train(ext, useData, hard=False, config=config, process_group=process_group, stats=stats)
 
 
-def train_Cdepth_hard(ext, useData, config=None, process_group=None):
-    return _train(ext, useData, hard=True, config=config, process_group=process_group)
+def train_Cdepth_hard(ext, useData, config=None, process_group=None, stats=None):
+    return _train(ext, useData, hard=True, config=config, process_group=process_group, stats=stats)

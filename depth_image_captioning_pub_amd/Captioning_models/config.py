@@ -27,3 +27,5 @@ class ConfigTrain(object):
         self.vocab_size = 10000
         self.seq_len = 20
         self.iters_per_epoch = 20
+        self.use_dpt = False            # True = BASELINE config 5: depth maps predicted by the DPT-Hybrid front-end in epoch 0
+        self.dpt_config = None          # synthetic.DptConfig (None = vitb_rn50_384)

@@ -49,6 +49,19 @@ def dep_trans(imgs: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def resize_planes(x: torch.Tensor, size: int) -> torch.Tensor:
+    """T.Resize((size, size)) of a square GPU tensor [B,C,S,S], bilinear, align_corners False, no antialias
+    (depth_transforms of depth_train.py:67,190)."""
+    if not x.is_cuda or x.shape[-1] != x.shape[-2]:
+        raise _lib.DicError("resize_planes: square GPU tensors only")
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, size, size), dtype=torch.float32, device=x.device)
+    check(_lib.load().dic_resize_bilinear(ptr(x), B * Cc, H, W, size, size, C.c_float(1.0), C.c_float(0.0), ptr(out),
+                                          stream_ptr()), "dic_resize_bilinear")
+    return out
+
+
 def standardize_depth_map(depth: torch.Tensor) -> torch.Tensor:
     """Per-image min-max to [0,1], NaN -> 0.5 first (DPT_model.py:43-61). depth: [B,1,H,W] on the GPU."""
     d = depth.contiguous().clone()

@@ -1,0 +1,364 @@
+// Building blocks of the frozen DPT-Hybrid depth front-end (BASELINE config 5):
+//   Captioning_models/Depth_caption_model/DPT_model.py:16-67, modules/midas/dpt_depth.py:26-107,
+//   modules/midas/blocks.py:231-341, modules/midas/vit.py:36-155,345-477 and - un-vendored, restated from its published
+//   definition - timm 0.4.12's vit_base_resnet50_384 (ResNetV2 stem with StdConv2dSame + GroupNorm, ViT-B/16 blocks).
+// Forward only (the reference runs it under @torch.no_grad, frozen).  The contractions (convolutions, linear layers) run
+// on the exact-fp32 MFMA kernels of gemm.hip through dic_conv2d_fwd / dic_gemm_f32; this file holds what those do not
+// cover: weight standardisation, asymmetric 'SAME' padding, GroupNorm, LayerNorm, multi-head attention, the bilinear x2
+// up-sampling of the fusion blocks and small element-wise passes.  All activations NHWC / [tokens][channels], fp32.
+#include "dic.h"
+#include "common.h"
+#include "nn_kernels.h"
+
+namespace dic {
+
+static inline int dpt_blocks(long long n, int per = 256) { return (int)std::min<long long>((n + per - 1) / per, 65535 * 16); }
+
+// ---- StdConv2d(Same): w_hat = (w - mean) / (std + eps), statistics per output filter, biased std ----------------
+__global__ void __launch_bounds__(256) weight_std_kernel(const float* __restrict__ w, int K, float eps,
+                                                          float* __restrict__ out) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* wo = w + (long long)blockIdx.x * K;
+  double s = 0.0, s2 = 0.0;
+  for (int k = tid; k < K; k += 256) { const double v = wo[k]; s += v; s2 += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (lane == 0) { red[0][wv] = s; red[1][wv] = s2; }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const double mean = s / K;
+  const double var = fmax(s2 / K - mean * mean, 0.0);
+  const double inv = 1.0 / (sqrt(var) + (double)eps);
+  for (int k = tid; k < K; k += 256) out[(long long)blockIdx.x * K + k] = (float)(((double)wo[k] - mean) * inv);
+}
+
+// ---- constant padding of an NHWC tensor (asymmetric 'SAME' padding of StdConv2dSame / MaxPool2dSame) ------------
+__global__ void __launch_bounds__(256) pad_nhwc_kernel(const float* __restrict__ x, int H, int W, int C, int top, int left,
+                                                        int OH, int OW, float value, long long total,
+                                                        float* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    long long r = i / C;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const long long b = r / OH;
+    const int h = oh - top, w = ow - left;
+    out[i] = ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? x[((b * H + h) * W + w) * C + c] : value;
+  }
+}
+
+// ---- GroupNorm over NHWC (+ optional residual add and ReLU): one workgroup per (image, group) -------------------
+// three passes over the group's HW x (C/G) elements (mean, centred variance, normalise): the group is L2-resident
+__global__ void __launch_bounds__(256) groupnorm_nhwc_kernel(const float* __restrict__ x, long long HW, int C, int G,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              const float* __restrict__ residual, int relu,
+                                                              float* __restrict__ out) {
+  __shared__ double red[4];
+  __shared__ float stat[2];
+  const int b = blockIdx.x / G, g = blockIdx.x % G, cg = C / G;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long base = (long long)b * HW * C + (long long)g * cg;
+  const long long n = HW * cg;
+  double s = 0.0;
+  for (long long i = tid; i < n; i += 256) s += x[base + (i / cg) * C + (i % cg)];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float mean = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+  __syncthreads();
+  double v = 0.0;
+  for (long long i = tid; i < n; i += 256) {
+    const float d = x[base + (i / cg) * C + (i % cg)] - mean;
+    v += (double)d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  if (tid == 0) { stat[0] = mean; stat[1] = (float)(1.0 / sqrt(((red[0] + red[1]) + (red[2] + red[3])) / (double)n + (double)eps)); }
+  __syncthreads();
+  const float rstd = stat[1];
+  for (long long i = tid; i < n; i += 256) {
+    const int c = (int)(i % cg);
+    const long long o = base + (i / cg) * C + c;
+    float y = (x[o] - mean) * rstd * gamma[g * cg + c] + beta[g * cg + c];
+    if (residual) y += residual[o];
+    if (relu) y = fmaxf(y, 0.f);
+    out[o] = y;
+  }
+}
+
+// ---- LayerNorm over the last dimension: one wave per row ---------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, long long rows, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float* __restrict__ out) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)C + eps);
+  for (int c = lane; c < C; c += 64) out[row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// ---- multi-head self-attention of a ViT block (timm Attention.forward): softmax(q k^T / sqrt(hd)) v ---------------
+// qkv: [B, N, 3, heads, 64] (the layout nn.Linear(dim, 3*dim) + reshape(B, N, 3, heads, hd) gives), out: [B, N, heads*64].
+// Workgroup = 64 queries of one (image, head); keys / values stream through LDS in tiles of 64 with an online softmax;
+// thread (ty, tx) owns a 4 x 4 block of the 64 x 64 score tile and of the 64 x 64 output tile (plain fp32 FMAs).
+constexpr int kHd = 64, kAt = 64, kAld = 68;        // head dim, tile, LDS row stride (16-B aligned, conflict-light)
+__global__ void __launch_bounds__(256) vit_attention_kernel(const float* __restrict__ qkv, int N, int heads, float scale,
+                                                             float* __restrict__ out) {
+  __shared__ __align__(16) float Qs[kAt][kAld], Ks[kAt][kAld], Vs[kAt][kAld], Ps[kAt][kAld];
+  const int qt = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const long long row_stride = (long long)3 * heads * kHd;
+  const float* base = qkv + (long long)b * N * row_stride + (long long)hh * kHd;
+  for (int i = tid; i < kAt * (kHd / 4); i += 256) {       // Q tile, pre-scaled
+    const int r = i / (kHd / 4), c4 = i % (kHd / 4);
+    const int q = qt * kAt + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < N) v = *reinterpret_cast<const float4*>(base + (long long)q * row_stride + c4 * 4);
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    *reinterpret_cast<float4*>(&Qs[r][c4 * 4]) = v;
+  }
+  float m[4], l[4], o[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m[i] = -INFINITY; l[i] = 0.f; for (int j = 0; j < 4; ++j) o[i][j] = 0.f; }
+  const int ntiles = (N + kAt - 1) / kAt;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();                                        // previous tile's Ks / Vs / Ps are no longer read
+    for (int i = tid; i < kAt * (kHd / 4); i += 256) {
+      const int r = i / (kHd / 4), c4 = i % (kHd / 4);
+      const int k = kt * kAt + r;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (k < N) {
+        const float* p = base + (long long)k * row_stride + c4 * 4;
+        kv = *reinterpret_cast<const float4*>(p + (long long)heads * kHd);
+        vv = *reinterpret_cast<const float4*>(p + (long long)2 * heads * kHd);
+      }
+      *reinterpret_cast<float4*>(&Ks[r][c4 * 4]) = kv;
+      *reinterpret_cast<float4*>(&Vs[r][c4 * 4]) = vv;
+    }
+    __syncthreads();
+    float s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[i][j] = 0.f;
+#pragma unroll 4
+    for (int d = 0; d < kHd; d += 4) {
+      float4 q4[4], k4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q4[i] = *reinterpret_cast<const float4*>(&Qs[ty * 4 + i][d]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k4[j] = *reinterpret_cast<const float4*>(&Ks[tx * 4 + j][d]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          s[i][j] += q4[i].x * k4[j].x + q4[i].y * k4[j].y + q4[i].z * k4[j].z + q4[i].w * k4[j].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                            // online softmax of row ty*4+i over this key tile
+      float tm = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kt * kAt + tx * 4 + j >= N) s[i][j] = -INFINITY;
+        tm = fmaxf(tm, s[i][j]);
+      }
+#pragma unroll
+      for (int w = 8; w > 0; w >>= 1) tm = fmaxf(tm, __shfl_xor(tm, w, 64));      // the 16 lanes tx = 0..15 of this row group
+      const float mn = fmaxf(m[i], tm);
+      const float corr = expf(m[i] - mn);                   // (first tile: exp(-inf) = 0)
+      float ps = 0.f;
+      float4 p4;
+      p4.x = expf(s[i][0] - mn); p4.y = expf(s[i][1] - mn); p4.z = expf(s[i][2] - mn); p4.w = expf(s[i][3] - mn);
+      ps = (p4.x + p4.y) + (p4.z + p4.w);
+#pragma unroll
+      for (int w = 8; w > 0; w >>= 1) ps += __shfl_xor(ps, w, 64);
+      l[i] = l[i] * corr + ps;
+      m[i] = mn;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[i][j] *= corr;
+      *reinterpret_cast<float4*>(&Ps[ty * 4 + i][tx * 4]) = p4;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < kAt; c += 4) {                       // O += P V
+      float4 p4[4], v4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const float4*>(&Ps[ty * 4 + i][c]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v4[u] = *reinterpret_cast<const float4*>(&Vs[c + u][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i][0] += p4[i].x * v4[0].x + p4[i].y * v4[1].x + p4[i].z * v4[2].x + p4[i].w * v4[3].x;
+        o[i][1] += p4[i].x * v4[0].y + p4[i].y * v4[1].y + p4[i].z * v4[2].y + p4[i].w * v4[3].y;
+        o[i][2] += p4[i].x * v4[0].z + p4[i].y * v4[1].z + p4[i].z * v4[2].z + p4[i].w * v4[3].z;
+        o[i][3] += p4[i].x * v4[0].w + p4[i].y * v4[1].w + p4[i].z * v4[2].w + p4[i].w * v4[3].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = qt * kAt + ty * 4 + i;
+    if (q < N) {
+      const float inv = 1.0f / l[i];
+      *reinterpret_cast<float4*>(out + ((long long)b * N + q) * heads * kHd + hh * kHd + tx * 4) =
+          make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+    }
+  }
+}
+
+// ---- bilinear x2 up-sampling, align_corners=True, NHWC (FeatureFusionBlock_custom, Interpolate) -------------------
+__global__ void __launch_bounds__(256) upsample2x_nhwc_kernel(const float* __restrict__ x, int H, int W, int C4,
+                                                               long long total, float* __restrict__ out) {
+  const int OH = 2 * H, OW = 2 * W;
+  const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f, rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C4);
+    long long r = i / C4;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const long long b = r / OH;
+    const float fh = rh * oh, fw = rw * ow;
+    const int h0 = (int)fh, w0 = (int)fw;
+    const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
+    const float ah = fh - h0, aw = fw - w0;
+    const float4* p = reinterpret_cast<const float4*>(x) + b * H * W * C4 + c;
+    const float4 v00 = p[((long long)h0 * W + w0) * C4], v01 = p[((long long)h0 * W + w1) * C4];
+    const float4 v10 = p[((long long)h1 * W + w0) * C4], v11 = p[((long long)h1 * W + w1) * C4];
+    const float w00 = (1.f - ah) * (1.f - aw), w01 = (1.f - ah) * aw, w10 = ah * (1.f - aw), w11 = ah * aw;
+    float4 y;
+    y.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+    y.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+    y.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+    y.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+    reinterpret_cast<float4*>(out)[i] = y;
+  }
+}
+
+// ---- element-wise passes: out = act(a + b[i % period]);  act 0 none, 1 ReLU, 3 GELU (exact, erf) ------------------
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__global__ void __launch_bounds__(256) add_act_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       long long n, long long period, int act, float* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float v = a[i];
+    if (b) v += b[i % period];
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 3) v = gelu_erf(v);
+    out[i] = v;
+  }
+}
+
+// ---- last layer of the depth head: 1x1 convolution to ONE channel + ReLU (dpt_depth.py:96-98) ----------------------
+__global__ void __launch_bounds__(256) pointwise_dot_kernel(const float* __restrict__ x, long long rows, int C,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             int relu, float* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += stride) {
+    const float4* p = reinterpret_cast<const float4*>(x + r * C);
+    float s = bias ? bias[0] : 0.f;
+    for (int c = 0; c < C / 4; ++c) {
+      const float4 v = p[c];
+      const float4 u = *reinterpret_cast<const float4*>(w + c * 4);
+      s += v.x * u.x + v.y * u.y + v.z * u.z + v.w * u.w;
+    }
+    out[r] = relu ? fmaxf(s, 0.f) : s;
+  }
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_weight_standardize(const float* w, int O, int K, float eps, float* out, void* stream) {
+  DIC_REQUIRE(w && out && O > 0 && K > 0, "weight_standardize: bad arguments");
+  hipLaunchKernelGGL(weight_std_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, K, eps, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_pad_nhwc(const float* x, int B, int H, int W, int C, int top, int left, int bottom, int right, float value,
+                 float* out, void* stream) {
+  DIC_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && top >= 0 && left >= 0 && bottom >= 0 && right >= 0,
+              "pad_nhwc: bad arguments");
+  const int OH = H + top + bottom, OW = W + left + right;
+  const long long total = (long long)B * OH * OW * C;
+  hipLaunchKernelGGL(pad_nhwc_kernel, dim3(dpt_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, H, W, C, top, left, OH, OW,
+                     value, total, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, float* out, void* stream) {
+  DIC_REQUIRE(x && out && B > 0 && C % 4 == 0 && k >= 1 && stride >= 1 && H >= k && W >= k, "maxpool_nhwc: bad arguments");
+  return bn_relu_maxpool(x, B, H, W, C, nullptr, 0, k, stride, 0, out, nullptr, (hipStream_t)stream, nullptr);
+}
+
+int dic_groupnorm_nhwc(const float* x, int B, long long HW, int C, int groups, const float* gamma, const float* beta,
+                       float eps, const float* residual, int relu, float* out, void* stream) {
+  DIC_REQUIRE(x && out && gamma && beta && B > 0 && HW > 0 && groups > 0 && C % groups == 0, "groupnorm_nhwc: bad arguments");
+  hipLaunchKernelGGL(groupnorm_nhwc_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, HW, C, groups, gamma, beta,
+                     eps, residual, relu, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_layernorm(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* out,
+                  void* stream) {
+  DIC_REQUIRE(x && out && gamma && beta && rows > 0 && C > 0, "layernorm: bad arguments");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, C, gamma,
+                     beta, eps, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_vit_attention(const float* qkv, int B, int N, int heads, int head_dim, float* out, void* stream) {
+  DIC_REQUIRE(qkv && out && B > 0 && N > 0 && heads > 0, "vit_attention: bad arguments");
+  DIC_REQUIRE(head_dim == kHd, "vit_attention: head dimension must be 64 (ViT-B/16: 768 / 12)");
+  hipLaunchKernelGGL(vit_attention_kernel, dim3((N + kAt - 1) / kAt, heads, B), dim3(256), 0, (hipStream_t)stream, qkv, N,
+                     heads, 1.0f / sqrtf((float)head_dim), out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_upsample2x_bilinear_nhwc(const float* x, int B, int H, int W, int C, float* out, void* stream) {
+  DIC_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C % 4 == 0, "upsample2x: bad arguments");
+  const long long total = (long long)B * 4 * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(dpt_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, H, W, C / 4, total,
+                     out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_add_act(const float* a, const float* b, long long n, long long period, int act, float* out, void* stream) {
+  DIC_REQUIRE(a && out && n > 0 && (b == nullptr || period > 0) && (act == 0 || act == 1 || act == 3), "add_act: bad arguments");
+  hipLaunchKernelGGL(add_act_kernel, dim3(dpt_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, period, act, out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+int dic_pointwise_dot(const float* x, long long rows, int C, const float* w, const float* bias, int relu, float* out,
+                      void* stream) {
+  DIC_REQUIRE(x && w && out && rows > 0 && C % 4 == 0, "pointwise_dot: bad arguments");
+  hipLaunchKernelGGL(pointwise_dot_kernel, dim3(dpt_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, C, w, bias, relu,
+                     out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+}  // extern "C"

@@ -30,7 +30,7 @@ __host__ __device__ __forceinline__ long long plane_offset(long long r, long lon
 }
 
 enum : int { OPK_ROWK = 0, OPK_COLK = 1, OPK_IM2COL = 2, OPK_GATHER = 3, OPK_IM2COL_COLK = 4, OPK_GATHER_COLK = 5 };
-enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_GELU = 3 };   // GELU: exact (erf) form, nn.GELU()
 
 struct ConvGeom {
   int H, W, C;      // input height / width / channels

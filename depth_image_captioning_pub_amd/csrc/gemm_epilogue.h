@@ -12,6 +12,7 @@ __device__ __forceinline__ float finalize_store(const GemmEpilogue& ep, int m, i
   if (ep.bias) v += ep.bias[n];
   if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
   else if (ep.act == ACT_SIGMOID) v = sigmoidf_(v);
+  else if (ep.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
   const long long orow = ep.row_map ? ep.row_map[m] : m;
   float* dst = (ep.C2 && n >= ep.nsplit) ? ep.C2 + orow * ep.ldc2 + (n - ep.nsplit) : ep.C + orow * ep.ldc + n;
   if (ep.accumulate) v += *dst;

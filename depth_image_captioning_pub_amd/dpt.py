@@ -1,0 +1,281 @@
+"""Frozen DPT-Hybrid depth estimator on the MI355X (BASELINE config 5): the layer sequence of
+DPT_Depthestimator.forward (Captioning_models/Depth_caption_model/DPT_model.py:63-67) = DPTDepthModel('vitb_rn50_384')
+(modules/midas/dpt_depth.py:64-107, blocks.py:231-341, vit.py:61-155) over timm 0.4.12's vit_base_resnet50_384, driven from
+the host; every tensor operation is a libdic_hip.so entry point (include/dic.h): convolutions and linear layers on the
+exact-fp32 MFMA contraction kernels (dic_conv2d_fwd, dic_gemm_f32), the rest in csrc/dpt_ops.hip.  torch only allocates
+and copies.  Activations are NHWC, so the reference's Transpose / Unflatten / flatten(2).transpose(1, 2) are no-ops.
+
+Weights: dict keyed like DPTDepthModel.state_dict() (synthetic.dpt_weights, or a real checkpoint through
+Captioning_models.Depth_caption_model.DPT_model.DPT_Depthestimator.load_state_dict).  Frozen: filters are standardised
+(StdConv2dSame) and re-laid out (OIHW -> OHWI) once at construction."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .synthetic import DptConfig, dpt_stage_spec
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 3
+
+
+def _same_pad(size: int, k: int, s: int) -> int:
+    """timm get_same_padding: total padding for out = ceil(in / stride); the smaller half goes in front."""
+    return max((math.ceil(size / s) - 1) * s + (k - 1) + 1 - size, 0)
+
+
+class DptRunner:
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[DptConfig] = None):
+        self.lib = _lib.load()
+        self.cfg = cfg or DptConfig()
+        if self.cfg.embed % self.cfg.heads or self.cfg.embed // self.cfg.heads != 64:
+            raise _lib.DicError("DptRunner: the attention kernel is built for 64-wide heads (ViT-B/16: 768 / 12)")
+        self.w: Dict[str, torch.Tensor] = {}
+        for k, v in weights.items():
+            if not v.is_cuda:
+                raise _lib.DicError(f"DptRunner: {k} must live on the GPU (no CPU fallback)")
+            self.w[k] = v.detach().to(torch.float32).contiguous()
+        self.dev = next(iter(self.w.values())).device
+        self.conv_w: Dict[str, torch.Tensor] = {}          # OHWI filters (standardised where the layer is a StdConv2d)
+        bb = "pretrained.model.patch_embed.backbone."
+        std_keys = [bb + "stem.conv"]
+        for p, _cin, _mid, _out, _s, ds in dpt_stage_spec(self.cfg):
+            std_keys += ([p + "downsample.conv"] if ds else []) + [p + "conv1", p + "conv2", p + "conv3"]
+        plain = ["pretrained.act_postprocess4.4", "scratch.output_conv.0", "scratch.output_conv.2"]
+        for n in (1, 2, 3, 4):
+            plain.append(f"scratch.layer{n}_rn")
+            plain += [f"scratch.refinenet{n}.resConfUnit{u}.conv{c}" for u in (1, 2) for c in (1, 2)]
+        for key in std_keys + plain:
+            w = self.w[key + ".weight"]
+            co, ci, kh, kw = w.shape
+            if key in std_keys:                              # [timm] StdConv2dSame.get_weight, eps = 1e-8
+                ws = torch.empty_like(w)
+                check(self.lib.dic_weight_standardize(ptr(w), co, ci * kh * kw, C.c_float(1e-8), ptr(ws), stream_ptr()),
+                      "dic_weight_standardize")
+                w = ws
+            if kh > 1 and ci > 1:
+                wo = torch.empty_like(w)
+                check(self.lib.dic_oihw_to_ohwi(ptr(w), ptr(wo), co, ci, kh, kw, stream_ptr()), "dic_oihw_to_ohwi")
+                w = wo
+            self.conv_w[key] = w
+        self.pos_cache: Dict[tuple, torch.Tensor] = {}
+
+    # ---- operator wrappers ----------------------------------------------------------------------
+    def _new(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def conv(self, x: torch.Tensor, key: str, stride: int = 1, pad: int = 0, bias: bool = True, nchw: bool = False):
+        """x NHWC [B,H,W,C] (or NCHW when nchw) -> NHWC [B,OH,OW,CO] on the exact-fp32 MFMA implicit-GEMM kernel."""
+        w = self.conv_w[key]
+        co, ci, kh, kw = self.w[key + ".weight"].shape
+        B, H, W = (x.shape[0], x.shape[2], x.shape[3]) if nchw else (x.shape[0], x.shape[1], x.shape[2])
+        oh, ow = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        y = self._new(B, oh, ow, co)
+        b = self.w[key + ".bias"] if bias else None
+        check(self.lib.dic_conv2d_fwd(ptr(x), B, H, W, ci, 1 if nchw else 0, ptr(w), ptr(b), co, kh, kw, stride, pad, ptr(y),
+                                      C.c_void_p(0), C.c_void_p(0), 0, C.c_void_p(0), stream_ptr()), "dic_conv2d_fwd")
+        return y
+
+    def pad(self, x: torch.Tensor, top: int, left: int, bottom: int, right: int, value: float = 0.0) -> torch.Tensor:
+        B, H, W, Cc = x.shape
+        y = self._new(B, H + top + bottom, W + left + right, Cc)
+        check(self.lib.dic_pad_nhwc(ptr(x), B, H, W, Cc, top, left, bottom, right, C.c_float(value), ptr(y), stream_ptr()),
+              "dic_pad_nhwc")
+        return y
+
+    def std_conv_same(self, x: torch.Tensor, key: str, stride: int = 1) -> torch.Tensor:
+        """[timm] StdConv2dSame: TensorFlow 'SAME' padding (asymmetric when the total is odd) + standardised filter."""
+        k = self.w[key + ".weight"].shape[-1]
+        ph, pw = _same_pad(x.shape[1], k, stride), _same_pad(x.shape[2], k, stride)
+        if ph == pw and ph % 2 == 0:
+            return self.conv(x, key, stride=stride, pad=ph // 2, bias=False)
+        return self.conv(self.pad(x, ph // 2, pw // 2, ph - ph // 2, pw - pw // 2), key, stride=stride, pad=0, bias=False)
+
+    def group_norm(self, x: torch.Tensor, prefix: str, relu: bool = True, residual: Optional[torch.Tensor] = None):
+        """[timm] GroupNormAct(32, eps 1e-5) [+ residual] [+ ReLU]."""
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        check(self.lib.dic_groupnorm_nhwc(ptr(x), B, C.c_longlong(H * W), Cc, 32, ptr(self.w[prefix + "weight"]),
+                                          ptr(self.w[prefix + "bias"]), C.c_float(1e-5), ptr(residual), 1 if relu else 0, ptr(y),
+                                          stream_ptr()), "dic_groupnorm_nhwc")
+        return y
+
+    def layer_norm(self, x: torch.Tensor, prefix: str) -> torch.Tensor:
+        y = torch.empty_like(x)
+        rows = x.numel() // x.shape[-1]
+        check(self.lib.dic_layernorm(ptr(x), C.c_longlong(rows), x.shape[-1], ptr(self.w[prefix + "weight"]),
+                                     ptr(self.w[prefix + "bias"]), C.c_float(1e-6), ptr(y), stream_ptr()), "dic_layernorm")
+        return y
+
+    def linear(self, x: torch.Tensor, key: str, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
+        """nn.Linear / 1x1 convolution over the last dimension; accumulate: out += result (residual branch)."""
+        w = self.w[key + ".weight"]
+        n, k = w.shape[0], w.numel() // w.shape[0]
+        m = x.numel() // k
+        if out is None:
+            out = self._new(*x.shape[:-1], n)
+        check(self.lib.dic_gemm_f32(m, n, k, ptr(x), C.c_longlong(k), 0, ptr(w), C.c_longlong(k), 0, ptr(out), C.c_longlong(n),
+                                    ptr(self.w[key + ".bias"]), act, 1 if accumulate else 0, 1, C.c_void_p(0), C.c_size_t(0), 0,
+                                    stream_ptr()), "dic_gemm_f32")
+        return out
+
+    def add_act(self, a: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE, out: Optional[torch.Tensor] = None):
+        out = torch.empty_like(a) if out is None else out
+        period = b.numel() if b is not None else 1
+        check(self.lib.dic_add_act(ptr(a), ptr(b), C.c_longlong(a.numel()), C.c_longlong(period), act, ptr(out), stream_ptr()),
+              "dic_add_act")
+        return out
+
+    def upsample2x(self, x: torch.Tensor) -> torch.Tensor:
+        B, H, W, Cc = x.shape
+        y = self._new(B, 2 * H, 2 * W, Cc)
+        check(self.lib.dic_upsample2x_bilinear_nhwc(ptr(x), B, H, W, Cc, ptr(y), stream_ptr()), "dic_upsample2x_bilinear_nhwc")
+        return y
+
+    # ---- network pieces ---------------------------------------------------------------------------
+    def pos_embed(self, gh: int, gw: int) -> torch.Tensor:
+        """vit.py:100-114 (_resize_pos_embed): the grid part is re-sampled bilinearly (align_corners False) to gh x gw."""
+        key = (gh, gw)
+        if key not in self.pos_cache:
+            pe = self.w["pretrained.model.pos_embed"]
+            g = self.cfg.pos_grid
+            if (gh, gw) == (g, g):
+                self.pos_cache[key] = pe.reshape(-1, pe.shape[-1]).contiguous()
+            else:
+                if gh != gw:
+                    raise _lib.DicError("DptRunner: square inputs only")
+                planes = pe[0, 1:].reshape(g, g, -1).permute(2, 0, 1).contiguous()           # [C, g, g]
+                out = self._new(planes.shape[0], gh, gw)
+                check(self.lib.dic_resize_bilinear(ptr(planes), planes.shape[0], g, g, gh, gh, C.c_float(1.0), C.c_float(0.0),
+                                                   ptr(out), stream_ptr()), "dic_resize_bilinear")
+                grid = out.permute(1, 2, 0).reshape(gh * gw, -1)
+                self.pos_cache[key] = torch.cat([pe[0, :1], grid], dim=0).contiguous()
+        return self.pos_cache[key]
+
+    def backbone(self, x: torch.Tensor):
+        """[timm] ResNetV2 stem + stages: NCHW image -> list of NHWC stage outputs."""
+        bb = "pretrained.model.patch_embed.backbone."
+        B, _, H, W = x.shape
+        ph, pw = _same_pad(H, 7, 2), _same_pad(W, 7, 2)
+        planes = self.pad(x.reshape(B * 3, H, W, 1), ph // 2, pw // 2, ph - ph // 2, pw - pw // 2)
+        xp = planes.reshape(B, 3, H + ph, W + pw)
+        y = self.conv(xp, bb + "stem.conv", stride=2, pad=0, bias=False, nchw=True)
+        y = self.group_norm(y, bb + "stem.norm.")
+        ph, pw = _same_pad(y.shape[1], 3, 2), _same_pad(y.shape[2], 3, 2)
+        yp = self.pad(y, ph // 2, pw // 2, ph - ph // 2, pw - pw // 2, value=float("-inf"))          # MaxPool2dSame
+        Bp, Hp, Wp, Cp = yp.shape
+        y = self._new(Bp, (Hp - 3) // 2 + 1, (Wp - 3) // 2 + 1, Cp)
+        check(self.lib.dic_maxpool_nhwc(ptr(yp), Bp, Hp, Wp, Cp, 3, 2, ptr(y), stream_ptr()), "dic_maxpool_nhwc")
+        outs, spec = [], dpt_stage_spec(self.cfg)
+        for i, (p, _cin, _mid, _out, stride, ds) in enumerate(spec):
+            shortcut = y
+            if ds:
+                shortcut = self.group_norm(self.std_conv_same(y, p + "downsample.conv", stride), p + "downsample.norm.", relu=False)
+            t = self.group_norm(self.std_conv_same(y, p + "conv1"), p + "norm1.")
+            t = self.group_norm(self.std_conv_same(t, p + "conv2", stride), p + "norm2.")
+            y = self.group_norm(self.std_conv_same(t, p + "conv3"), p + "norm3.", relu=True, residual=shortcut)   # act3(x + shortcut)
+            if i + 1 == len(spec) or spec[i + 1][0].split(".blocks.")[0] != p.split(".blocks.")[0]:
+                outs.append(y)
+        return outs
+
+    def vit_block(self, x: torch.Tensor, p: str) -> None:
+        """[timm] Block.forward, in place on x [B,N,C]."""
+        B, N, Cc = x.shape
+        h = self.layer_norm(x, p + "norm1.")
+        qkv = self.linear(h, p + "attn.qkv")
+        a = torch.empty_like(x)
+        check(self.lib.dic_vit_attention(ptr(qkv), B, N, self.cfg.heads, Cc // self.cfg.heads, ptr(a), stream_ptr()),
+              "dic_vit_attention")
+        self.linear(a, p + "attn.proj", out=x, accumulate=True)
+        h = self.layer_norm(x, p + "norm2.")
+        m = self.linear(h, p + "mlp.fc1", act=ACT_GELU)
+        self.linear(m, p + "mlp.fc2", out=x, accumulate=True)
+
+    def reassemble(self, tok: torch.Tensor, n: int, gh: int, gw: int) -> torch.Tensor:
+        """ProjectReadout (vit.py:36-48) + Transpose/Unflatten (no-op in NHWC) + 1x1 convolution (vit.py:441-466)."""
+        B, N, Cc = tok.shape
+        r = self._new(B, N - 1, 2 * Cc)
+        r[:, :, :Cc].copy_(tok[:, 1:])
+        r[:, :, Cc:].copy_(tok[:, :1].expand(B, N - 1, Cc))
+        y = self.linear(r, f"pretrained.act_postprocess{n}.0.project.0", act=ACT_GELU)
+        return self.linear(y, f"pretrained.act_postprocess{n}.3").reshape(B, gh, gw, -1)
+
+    def residual_conv_unit(self, x: torch.Tensor, p: str) -> torch.Tensor:
+        """blocks.py:268-289."""
+        t = self.conv(self.add_act(x, None, ACT_RELU), p + "conv1", pad=1)
+        t = self.conv(self.add_act(t, None, ACT_RELU, out=t), p + "conv2", pad=1)
+        return self.add_act(t, x, out=t)
+
+    def fusion(self, p: str, x: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """blocks.py:318-341 (FeatureFusionBlock_custom.forward)."""
+        if skip is not None:
+            x = self.add_act(x, self.residual_conv_unit(skip, p + "resConfUnit1."))
+        x = self.upsample2x(self.residual_conv_unit(x, p + "resConfUnit2."))
+        return self.linear(x, p + "out_conv")
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,3,H,W] (normalised to [-1,1], H = W, multiple of 32) -> depth [B,H,W] >= 0."""
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise _lib.DicError("DptRunner.forward: float32 GPU images expected (no CPU fallback)")
+        x = x.contiguous()
+        B, c, H, W = x.shape
+        if c != 3 or H != W or H % 32:
+            raise _lib.DicError("DptRunner.forward: images must be [B,3,S,S] with S a multiple of 32")
+        cfg, P = self.cfg, "pretrained.model."
+        stages = self.backbone(x)
+        gh, gw = H // 16, W // 16
+        tok = self.linear(stages[-1], P + "patch_embed.proj")                       # HybridEmbed.proj (1x1) -> [B,gh,gw,C]
+        E = tok.shape[-1]
+        X = self._new(B, 1 + gh * gw, E)
+        X[:, 0].copy_(self.w[P + "cls_token"].reshape(1, E).expand(B, E))
+        X[:, 1:].copy_(tok.reshape(B, gh * gw, E))
+        self.add_act(X, self.pos_embed(gh, gw), out=X)
+        acts = {}
+        for i in range(cfg.depth):
+            self.vit_block(X, P + f"blocks.{i}.")
+            if i in cfg.hooks:
+                acts[i] = X.clone()
+        layer_3 = self.reassemble(acts[cfg.hooks[0]], 3, gh, gw)
+        layer_4 = self.conv(self.reassemble(acts[cfg.hooks[1]], 4, gh, gw), "pretrained.act_postprocess4.4", stride=2, pad=1)
+        rn = [self.conv(l, f"scratch.layer{n}_rn", pad=1, bias=False)
+              for n, l in zip((1, 2, 3, 4), (stages[0], stages[1], layer_3, layer_4))]
+        path = self.fusion("scratch.refinenet4.", rn[3])
+        path = self.fusion("scratch.refinenet3.", path, rn[2])
+        path = self.fusion("scratch.refinenet2.", path, rn[1])
+        path = self.fusion("scratch.refinenet1.", path, rn[0])
+        y = self.upsample2x(self.conv(path, "scratch.output_conv.0", pad=1))
+        y = self.conv(y, "scratch.output_conv.2", pad=1)
+        self.add_act(y, None, ACT_RELU, out=y)
+        out = self._new(B, H, W)
+        check(self.lib.dic_pointwise_dot(ptr(y), C.c_longlong(B * H * W), y.shape[-1], ptr(self.w["scratch.output_conv.4.weight"]),
+                                         ptr(self.w["scratch.output_conv.4.bias"]), 1, ptr(out), stream_ptr()),
+              "dic_pointwise_dot")
+        return out
+
+    def flops_per_image(self, size: int = 384) -> float:
+        """Algorithmic FLOPs (2 x multiply-adds of every convolution / linear layer / attention product) of one forward."""
+        cfg = self.cfg
+        f = 2.0 * (size // 2) ** 2 * cfg.stem * 147
+        hw = (size // 4) ** 2
+        for _p, cin, mid, out, stride, ds in dpt_stage_spec(cfg):
+            hw_out = hw // (stride * stride)
+            f += 2.0 * (hw * cin * mid + hw_out * mid * mid * 9 + hw_out * mid * out + (hw_out * cin * out if ds else 0))
+            hw = hw_out
+        n, E = hw + 1, cfg.embed
+        f += 2.0 * hw * cfg.channels[-1] * E
+        f += cfg.depth * (2.0 * n * (3 * E * E + E * E + 2 * E * cfg.mlp) + 4.0 * n * n * E)
+        f += 2 * (2.0 * hw * 2 * E * E + 2.0 * hw * E * E) + 2.0 * (hw // 4) * E * E * 9
+        Fd = cfg.features
+        sizes = [(size // 4) ** 2, (size // 8) ** 2, hw, hw // 4]
+        for cin, s in zip((cfg.channels[0], cfg.channels[1], E, E), sizes):
+            f += 2.0 * s * cin * Fd * 9
+        for i, s in enumerate(sizes):
+            f += (2 if i == 3 else 4) * 2.0 * s * Fd * Fd * 9 + 2.0 * 4 * s * Fd * Fd
+        f += 2.0 * (size // 2) ** 2 * Fd * (Fd // 2) * 9 + 2.0 * size * size * (Fd // 2) * 32 * 9 + 2.0 * size * size * 32
+        return f

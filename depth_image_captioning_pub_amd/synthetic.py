@@ -123,6 +123,12 @@ def rgb_images(batch: int, seed: int = 123, size: int = 224) -> torch.Tensor:
     return torch.from_numpy((x - m) / s)
 
 
+def raw_images(batch: int, seed: int = 123, size: int = 224) -> torch.Tensor:
+    """The same U[0,1) draw as rgb_images, before any normalisation (what ToTensor() yields: util.py:100-101 then derive
+    the ImageNet-normalised batch and the 384x384 copy for the depth estimator from it)."""
+    return torch.from_numpy(_rng(seed).random((batch, 3, size, size), dtype=np.float32))
+
+
 def depth_maps(batch: int, seed: int = 123, size: int = 224) -> torch.Tensor:
     """U[0,1) then per-image min-max to exactly [0,1] (mirrors DPT_model.py:50-59)."""
     x = _rng(seed + 1000).random((batch, 1, size, size), dtype=np.float32)
@@ -175,3 +181,103 @@ def gumbel_uniforms(tmax: int, batch: int, seed: int = 123) -> torch.Tensor:
     """u ~ U(0,1) [T,B,196] for the hard path; explicit input (Q6, attention.py:17)."""
     u = _rng(seed + 5000).random((tmax, batch, L_CELLS), dtype=np.float32)
     return torch.from_numpy(np.clip(u, 1e-6, 1.0 - 1e-6).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# DPT-Hybrid depth front-end (BASELINE config 5): DPTDepthModel(backbone='vitb_rn50_384')
+#   (Depth_caption_model/modules/midas/dpt_depth.py:26-107, blocks.py:49-75,231-341, vit.py:345-477) over timm 0.4.12's
+#   vit_base_resnet50_384.  The checkpoint (DPT_model.py:23) and the timm weights are unreachable offline: procedural
+#   weights with the state_dict names and shapes DPTDepthModel.state_dict() has.
+# ------------------------------------------------------------------------------------------------
+class DptConfig:
+    """Architecture sizes.  Default = vitb_rn50_384; tests shrink `layers` / `depth` (hooks follow) to keep the oracle fast."""
+
+    def __init__(self, layers=(3, 4, 9), depth=12, hooks=(8, 11), heads=12, embed=768, mlp=3072, features=256,
+                 pos_grid=24, stem=64, channels=(256, 512, 1024)):
+        self.layers, self.depth, self.hooks, self.heads = tuple(layers), depth, tuple(hooks), heads
+        self.embed, self.mlp, self.features, self.pos_grid = embed, mlp, features, pos_grid
+        self.stem, self.channels = stem, tuple(channels)
+
+
+def dpt_stage_spec(cfg: "DptConfig"):
+    """[(prefix, in_chs, mid_chs, out_chs, stride, has_downsample)] of the ResNetV2 bottlenecks in execution order."""
+    spec, prev = [], cfg.stem
+    for s, (nb, out) in enumerate(zip(cfg.layers, cfg.channels)):
+        for b in range(nb):
+            p = f"pretrained.model.patch_embed.backbone.stages.{s}.blocks.{b}."
+            spec.append((p, prev, out // 4, out, (1 if s == 0 else 2) if b == 0 else 1, b == 0))
+            prev = out
+    return spec
+
+
+def dpt_weights(seed: int = 130, cfg: "DptConfig" = None) -> Dict[str, torch.Tensor]:
+    cfg = cfg or DptConfig()
+    r = _rng(seed)
+    w: Dict[str, torch.Tensor] = {}
+
+    def normal(shape, std):
+        return torch.from_numpy((r.standard_normal(shape) * std).astype(np.float32))
+
+    def conv(key, co, ci, k, bias=True):
+        bound = 1.0 / math.sqrt(ci * k * k)                       # nn.Conv2d default initialiser
+        w[key + ".weight"] = _uniform(r, (co, ci, k, k), bound * math.sqrt(3.0))
+        if bias:
+            w[key + ".bias"] = _uniform(r, (co,), bound)
+
+    def norm(key, c):
+        w[key + ".weight"] = torch.from_numpy((1.0 + 0.1 * r.standard_normal(c)).astype(np.float32))
+        w[key + ".bias"] = torch.from_numpy((0.1 * r.standard_normal(c)).astype(np.float32))
+
+    def linear(key, out_f, in_f, std=0.02):
+        w[key + ".weight"] = normal((out_f, in_f), std)
+        w[key + ".bias"] = normal((out_f,), 0.02)
+
+    bb = "pretrained.model.patch_embed.backbone."
+    w[bb + "stem.conv.weight"] = normal((cfg.stem, 3, 7, 7), 0.1)           # StdConv2dSame: standardised at use
+    norm(bb + "stem.norm", cfg.stem)
+    for p, cin, mid, out, _stride, ds in dpt_stage_spec(cfg):
+        if ds:
+            w[p + "downsample.conv.weight"] = normal((out, cin, 1, 1), 0.1)
+            norm(p + "downsample.norm", out)
+        w[p + "conv1.weight"] = normal((mid, cin, 1, 1), 0.1)
+        norm(p + "norm1", mid)
+        w[p + "conv2.weight"] = normal((mid, mid, 3, 3), 0.1)
+        norm(p + "norm2", mid)
+        w[p + "conv3.weight"] = normal((out, mid, 1, 1), 0.1)
+        norm(p + "norm3", out)
+    P = "pretrained.model."
+    conv(P + "patch_embed.proj", cfg.embed, cfg.channels[-1], 1)
+    w[P + "cls_token"] = normal((1, 1, cfg.embed), 0.02)
+    w[P + "pos_embed"] = normal((1, 1 + cfg.pos_grid * cfg.pos_grid, cfg.embed), 0.02)
+    for i in range(cfg.depth):
+        b = P + f"blocks.{i}."
+        norm(b + "norm1", cfg.embed)
+        linear(b + "attn.qkv", 3 * cfg.embed, cfg.embed, std=0.05)
+        linear(b + "attn.proj", cfg.embed, cfg.embed)
+        norm(b + "norm2", cfg.embed)
+        linear(b + "mlp.fc1", cfg.mlp, cfg.embed)
+        linear(b + "mlp.fc2", cfg.embed, cfg.mlp)
+    norm(P + "norm", cfg.embed)
+    for n in (3, 4):
+        linear(f"pretrained.act_postprocess{n}.0.project.0", cfg.embed, 2 * cfg.embed)
+        conv(f"pretrained.act_postprocess{n}.3", cfg.embed, cfg.embed, 1)
+    conv("pretrained.act_postprocess4.4", cfg.embed, cfg.embed, 3)
+    F_ = cfg.features
+    for n, cin in zip((1, 2, 3, 4), (cfg.channels[0], cfg.channels[1], cfg.embed, cfg.embed)):
+        conv(f"scratch.layer{n}_rn", F_, cin, 3, bias=False)
+        rn = f"scratch.refinenet{n}."
+        conv(rn + "out_conv", F_, F_, 1)
+        for u in (1, 2):
+            conv(rn + f"resConfUnit{u}.conv1", F_, F_, 3)
+            conv(rn + f"resConfUnit{u}.conv2", F_, F_, 3)
+    conv("scratch.output_conv.0", F_ // 2, F_, 3)
+    conv("scratch.output_conv.2", 32, F_ // 2, 3)
+    conv("scratch.output_conv.4", 1, 32, 1)
+    w["scratch.output_conv.4.bias"] = torch.full((1,), 0.3)       # keeps the final ReLU from clipping most of the map
+    return w
+
+
+def dpt_images(batch: int, seed: int = 123, size: int = 384) -> torch.Tensor:
+    """What util.dep_trans hands the estimator: RGB in [0,1) -> Normalize(0.5, 0.5) = [-1,1)   (util.py:14-17)."""
+    x = _rng(seed + 6000).random((batch, 3, size, size), dtype=np.float32)
+    return torch.from_numpy((x - 0.5) / 0.5)
