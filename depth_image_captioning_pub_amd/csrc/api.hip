@@ -4,7 +4,8 @@
 
 using namespace dic;
 
-namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); }
+namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); void decoder_debug_persistent(int on);
+                void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p); }
 
 extern "C" {
 
@@ -37,12 +38,16 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
 }
 
 int dic_debug_force_staged_gemm(int on) {
+  if (on == 140 || on == 141) { dic::decoder_debug_persistent(on - 140); return 0; }
+  if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement   // decoder forward: per-step launches / persistent loop
   if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
   if (on == 11 || on == 21 || on == 22 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 52) || (on >= 60 && on <= 63)) gemm_bf3_force_tile(on == 20 ? 0 : on);
   else gemm_force_v1(on);
   return 0;
 }
+/* development aid (not in dic.h): device buffer [T][8] receiving phase time stamps of the persistent decoder loop */
+int dic_debug_decoder_stamps(unsigned long long* dev_buf) { dic::decoder_persist_debug_buffer(dev_buf); return 0; }
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
   DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");

@@ -67,6 +67,10 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.dalpha_c = c.take<float>(BT * kLc);
   w.dXe = c.take<float>(BT * kE);
   w.dlen = c.take<int>((size_t)B);
+  w.Gemb = c.take<float>(BT * kG);
+  w.pslab = c.take<float>((size_t)2 * 16 * 16 * 4 * kG);
+  w.psync = c.take<unsigned int>(32);
+  w.poff = c.take<int>((size_t)T + 2);
   w.logits_step = c.take<float>((size_t)B * V);
   w.ids = c.take<long long>((size_t)B);
   w.bytes = c.off;
@@ -1026,6 +1030,11 @@ __global__ void __launch_bounds__(256) fold_dalphas_kernel(const float* __restri
   dc[i] = 0.25f * ((r[0] + r[1]) + (r[14] + r[15]));
 }
 
+// The persistent forward loop is an opt-in experiment (switch 141): correct (tests/test_decoder_gpu.py runs it against the
+// oracle) but at batch 64 it takes 20 us per step against 21.7 us for the two launches it replaces - see DESIGN.md 5.3.
+static int g_persistent = 0;
+void decoder_debug_persistent(int on) { g_persistent = on; }
+
 // runs STMT with a compile-time cell count L_ (196 = reference layout, 49 = compact)
 #define DIC_CELLS_SWITCH(CELLS, STMT)   \
   if ((CELLS) == kL) {                  \
@@ -1111,7 +1120,13 @@ static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* fe
                      d_len, T, V, ws.Xall);
   DIC_LAUNCH_CHECK();
 
-  for (int t = 0; t < T; ++t) {
+  const bool persistent = g_persistent && decoder_persist_eligible(B, T, mode);
+  if (persistent) {
+    // embedding part of every step's gate pre-activations (time-invariant under teacher forcing) + (b_ih + b_hh)
+    DIC_TRY(gemm(B * T, kG, kE, op_rowk(ws.Xall, kXK), op_rowk(ws.Wcat, kXK), ep_store(ws.Gemb, kG, ws.bcat), st));
+    DIC_TRY(decoder_fwd_persistent(ws, w, B, T, cells, drop_mult, alphas, pl.off.data(), st));
+  }
+  for (int t = 0; t < T && !persistent; ++t) {
     const int nb = pl.bs[t];
     // steps t >= 1 carry the LSTM cell of step t-1 in their prologue (FusedLstm); rows that ended at t-1 are
     // still in the grid (nb_prev >= nb) for that part only
@@ -1130,7 +1145,7 @@ static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* fe
     DIC_TRY(gemm_slabs(nb, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
   }
-  if (T > 0) {       // the last step's cell has no following attention launch
+  if (T > 0 && !persistent) {       // the last step's cell has no following attention launch
     const int tl = T - 1;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(pl.bs[tl]), dim3(kH), 0, st, ws.slab_g, kS_LSTM, pl.bs[tl], ws.bcat, tl, T,
                        drop_mult, pl.off[tl], ws.Hall, ws.Call, ws.Gact, ws.Hdrop);

@@ -314,6 +314,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
  *   120 121      tail fix-up and BatchNorm finalize in separate launches / fused (default)
  *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
+ *   140 141      decoder forward loop: one launch pair per step (default) / one persistent launch for all steps
+ *   142 143      persistent loop placement: a row group's 16 chunk workgroups on one XCD (default) / chunks 2x, 2x+1 on XCD x
  *   130..134     depth-encoder layer 1: generic MFMA gather path / packed-FMA kernels with 256, 512 (default), 768, 1024 workgroups
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + 2*(tile_m/64 - 1) + (tile_n/64 - 1). */
 int dic_debug_force_staged_gemm(int on);

@@ -326,8 +326,10 @@ def adamw_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], exp_avg: Dic
 def train_step_soft(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_state: Dict[str, Tensor],
                     feats_rgb: Tensor, depth_map: Tensor, captions: Tensor, lengths: Sequence[int],
                     drop_mult: Optional[Tensor], decisions: Optional[Dict[str, Tensor]] = None,
-                    report: Optional[dict] = None):
+                    report: Optional[dict] = None, hard_u: Optional[Tensor] = None, temp: Optional[Tensor] = None):
     """Forward + loss + backward.  Returns (loss, packed_logits, alphas, grads_dec, grads_enc).
+    hard_u [Tmax,B,196] + temp: the depth-HARD step of train_Cdepth_hard (depth_train.py:500-560): Gumbel-softmax
+    attention with the uniform draws as explicit input, loss = cross-entropy only (:530-532).
     decisions: replay the depth encoder's ReLU / max-pool selections (depth_encoder_forward_replay; `report` receives
     its tie report) instead of taking them afresh - parity tests only."""
     dw = {k: v.detach().clone().requires_grad_(True) for k, v in dec_w.items()}
@@ -338,8 +340,8 @@ def train_step_soft(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_stat
         fd, rep = depth_encoder_forward_replay(ew, enc_state, depth_map.detach(), decisions)
         if report is not None:
             report.update(rep)
-    packed, bsz, alphas = decoder_forward(dw, feats_rgb, fd, captions, lengths, drop_mult)
-    loss = caption_loss(packed, pack_targets(captions, lengths), alphas)          # :210-216
+    packed, bsz, alphas = decoder_forward(dw, feats_rgb, fd, captions, lengths, drop_mult, hard_u=hard_u, temp=temp)
+    loss = caption_loss(packed, pack_targets(captions, lengths), None if hard_u is not None else alphas)   # :210-216 / :530
     loss.backward()                                                                # :219
     gd = {k: v.grad for k, v in dw.items()}
     ge = {k: v.grad for k, v in ew.items()}

@@ -34,17 +34,22 @@ def test_bench_gpus2_self_launch_over_gloo_on_one_gpu(lib):
     assert d["value"] > 0 and d["loss"] == d["loss"]            # finite
 
 
-def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path):
+@pytest.mark.parametrize("full_size", [False, True])
+def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path, full_size, monkeypatch):
     """N-rank == 1-rank: two real ranks (own process each, gloo all-reduce of the two gradient buckets) take one training
     step on the two halves of a RAGGED length-sorted global batch; a single process then replays the same step shard by
     shard (virtual_world=2: same per-shard BatchNorm statistics = DDP semantics, same token-weighted gradient scaling),
     sums the two gradient buffers and applies AdamW.  Post-step parameters must agree to 1e-5 (all-reduce vs in-order sum
-    differ in nothing but the transport), both ranks must hold identical parameters, and the token-weighted mean of the
-    rank losses' CE parts is what a single device would report."""
+    differ in nothing but the transport), both ranks must hold identical parameters.
+    full_size: BASELINE config 3 per rank - 2 ranks x 32 images at 224x224, ResNet-152, seq-len 20, V = 10 000 (the 8-GPU
+    configuration's per-rank shape; the transport is gloo because two ranks share this box's one GPU)."""
+    import importlib
     import socket
     from depth_image_captioning_pub_amd.engine import CaptionTrainer
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    monkeypatch.setenv("DP_FULL_SIZE", "1" if full_size else "0")
     import dp_step_worker as wk
+    wk = importlib.reload(wk)
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -52,6 +57,7 @@ def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path):
     s.close()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(SHARE)
+    env["DP_FULL_SIZE"] = "1" if full_size else "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_step_worker.py"), str(tmp_path)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -59,9 +65,10 @@ def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path):
     ranks = [torch.load(tmp_path / f"rank{i}.pt") for i in range(2)]
     assert torch.equal(ranks[0]["params"], ranks[1]["params"]), "ranks diverged after the all-reduced step"
     assert ranks[0]["drop_seed"] != ranks[1]["drop_seed"], "every rank must draw its own dropout masks"
-    assert ranks[0]["tokens"] > ranks[1]["tokens"]                      # ragged: rank 0 holds the longer captions
+    if not full_size:
+        assert ranks[0]["tokens"] > ranks[1]["tokens"]                  # ragged: rank 0 holds the longer captions
 
-    tr = CaptionTrainer(wk.VOCAB, device="cuda:0", seed=7, resnet_layers=(1, 1, 1, 1), conv_mode="bf16x3")
+    tr = CaptionTrainer(wk.VOCAB, device="cuda:0", seed=7, resnet_layers=wk.LAYERS, conv_mode="bf16x3")
     gsum, losses = None, []
     for rank in range(2):
         imgs, depth, caps, ln, drop, gtok = wk.shard(rank, 2)

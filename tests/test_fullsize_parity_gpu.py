@@ -146,3 +146,54 @@ def test_full_size_step_vs_oracle(lib, B, conv_mode, compact):
     assert int((~decidable).sum()) <= margin.numel() // 20, "rounding band too wide for the comparison to mean anything"
     del tr
     torch.cuda.empty_cache()
+
+
+def test_full_size_hard_attention_step_vs_oracle(lib):
+    """BASELINE config 4 per rank (depth-hard, batch 32 = 128 / 4 GPUs, seq-len 20, V = 10 000, temp 1.0, 196 cells,
+    explicit Gumbel noise [T,B,196] and dropout mask): the same stage-B comparison as the soft step - the oracle gets the HIP
+    path's ResNet-152 features and replays its depth-encoder selections; loss (cross-entropy only, depth_train.py:530)
+    1e-5, logits 1e-4, argmax identical on all 640 rows, all 29 gradients against the fp64 replay (1e-3 of scale or twice
+    the fp32 oracle's own distance) - and the end-to-end loss against the stand-alone oracle 1e-4."""
+    B = 32
+    o = _inputs(B)
+    u = syn.gumbel_uniforms(T, B, seed=223)
+    temp = torch.tensor(1.0)
+    tr = CaptionTrainer(VOCAB, device=DEV, seed=123, hard=True, decoder_init=o["dec"], depth_init=o["enc"],
+                        depth_state=copy.deepcopy(o["st"]), resnet_init=copy.deepcopy(o["rn"]), conv_mode="bf16x3")
+    tr.keep_outputs = True
+    loss = tr.train_step(o["imgs"].to(DEV), o["depth"].to(DEV), o["caps"].to(DEV), o["lens"], drop_mult=o["drop"].to(DEV),
+                         gumbel_u=u.to(DEV), temp=1.0, apply_update=False)
+    torch.cuda.synchronize()
+    loss = float(loss.item())
+    feats = tr.last["features"].cpu()
+    assert feats.shape[1] == 196
+    dec_sel = {k: v.cpu() for k, v in native.depth_encoder_decisions(
+        native.DepthTape(tr.enc_ws, o["depth"].to(DEV), tr.enc_w, False)).items()}
+    rep = {}
+    l_ref, packed_ref, _, gd, ge = orc.train_step_soft(o["dec"], o["enc"], copy.deepcopy(o["st"]), feats, o["depth"], o["caps"],
+                                                       o["lens"], o["drop"], decisions=dec_sel, report=rep, hard_u=u, temp=temp)
+    assert all(short <= 3e-5 for _, short in rep.values()), rep
+    assert abs(loss - float(l_ref)) <= 1e-5, (loss, float(l_ref))
+    logits = tr.last["logits"]
+    e, s = _err(logits, packed_ref)
+    assert e <= 1e-4 * s, f"logits {e:.3e} vs {s:.3e}"
+    assert torch.equal(logits.argmax(1).cpu(), packed_ref.argmax(1))
+    d64 = lambda d: {k: v.double() for k, v in d.items()}                                    # noqa: E731
+    _, _, _, gd64, ge64 = orc.train_step_soft(d64(o["dec"]), d64(o["enc"]), d64(o["st"]), feats.double(), o["depth"].double(),
+                                              o["caps"], o["lens"], o["drop"].double(), decisions=dec_sel, hard_u=u.double(),
+                                              temp=temp.double())
+    bad = []
+    for name, ref in list(gd64.items()) + list(ge64.items()):
+        is_dec = name in gd64
+        e, s = _err((tr.dec_g if is_dec else tr.enc_g)[name], ref)
+        e32, _ = _err((gd if is_dec else ge)[name], ref)
+        if name in ZERO_GRAD:
+            sib = float((gd64 if is_dec else ge64)[name[:-4] + "weight"].abs().max())
+            if not e <= 1e-2 * sib:
+                bad.append(f"{name}: |noise| {e:.3e} vs {sib:.2e}")
+        elif not (e <= 1e-3 * s or e <= 2.0 * e32):
+            bad.append(f"{name}: HIP {e:.3e} (fp32 oracle {e32:.3e}) from fp64, scale {s:.3e}")
+    assert not bad, "; ".join(bad)
+    own = orc.train_step_soft(o["dec"], o["enc"], copy.deepcopy(o["st"]), o["feats"], o["depth"], o["caps"], o["lens"], o["drop"],
+                              hard_u=u, temp=temp)
+    assert abs(loss - float(own[0])) <= 1e-4, (loss, float(own[0]))
