@@ -135,6 +135,30 @@ def test_depth_main_cli_smoke(lib, tmp_path, monkeypatch):
         enc.load_state_dict(torch.load(d / f"{tag}_encoder_best_synthetic0.pth", weights_only=True), strict=True)
         ddec.load_state_dict(torch.load(d / f"{tag}_decoder_best_synthetic0.pth", weights_only=True), strict=True)
         denc.load_state_dict(torch.load(d / f"{tag}_D_encoder_best_synthetic0.pth", weights_only=True), strict=True)
+    # ---- the evaluation loop of depth_evaluation.py:146-176 on the checkpoints just written --------------------------
+    from depth_image_captioning_pub_amd import depth_evaluation as ev
+    from depth_image_captioning_pub_amd.Captioning_models.Depth_caption_model.DPT_model import DPT_Depthestimator
+    cfg = Tiny()
+    cfg.dpt_config = syn.DptConfig(layers=(1, 1, 1), depth=2, hooks=(0, 1))
+    dpt = DPT_Depthestimator(cfg.dpt_config, seed=7)
+    res = ev.Cdepth_evaluation("soft", "synthetic", config=cfg, n_batches=2, dpt=dpt)["run0"]
+    assert res["ids"].shape == (4, 30) and res["ids"].dtype == np.int64 and len(res["hypotheses"]) == 4
+    w2i, i2w = ev.synthetic_vocabulary(120)
+    assert all(set(h.split()) <= set(w2i) - {"<end>"} for h in res["hypotheses"])
+    # the decode against the oracle: same checkpoint, HIP encoder / depth-encoder features, oracle greedy loop
+    from depth_image_captioning_pub_amd.Captioning_models import util
+    d = tmp_path / "CNN_depth_soft"
+    dec_sd = torch.load(d / "depth_soft_decoder_best_synthetic0.pth", weights_only=True)
+    enc, denc = CNNEncoder_Atten(14).to(DEV).eval(), Depth_CNN_endoder(14).to(DEV).eval()
+    enc.load_state_dict(torch.load(d / "depth_soft_encoder_best_synthetic0.pth", weights_only=True))
+    denc.load_state_dict(torch.load(d / "depth_soft_D_encoder_best_synthetic0.pth", weights_only=True))
+    raw = syn.raw_images(2, seed=5000).to(DEV)
+    imgs, imgs_dep = util.device_transforms(raw)
+    feats, fdep = enc(imgs), denc(dpt.to(DEV).depth_maps_for_training(imgs_dep))
+    ref_ids = orc.batch_sample({k: v.cpu() for k, v in dec_sd.items()}, feats.cpu(), fdep.cpu(), w2i["<start>"], 30)
+    assert np.array_equal(res["ids"][:2], ref_ids.numpy())
+    assert ev.ids_to_captions(np.array([[0, 1, w2i["<end>"], 5]]), i2w) == ["w0 w1"]
+
     assert depth_main.main(["depth_main", "soft", "mlp", "synthetic"]) == 0          # no-op branch of the reference
     assert depth_main.main(["depth_main", "soft", "cnn", "nonsense"]) == 1
 
