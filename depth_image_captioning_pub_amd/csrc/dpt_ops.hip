@@ -50,46 +50,80 @@ __global__ void __launch_bounds__(256) pad_nhwc_kernel(const float* __restrict__
   }
 }
 
-// ---- GroupNorm over NHWC (+ optional residual add and ReLU): one workgroup per (image, group) -------------------
-// three passes over the group's HW x (C/G) elements (mean, centred variance, normalise): the group is L2-resident
-__global__ void __launch_bounds__(256) groupnorm_nhwc_kernel(const float* __restrict__ x, long long HW, int C, int G,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float eps,
-                                                              const float* __restrict__ residual, int relu,
-                                                              float* __restrict__ out) {
-  __shared__ double red[4];
-  __shared__ float stat[2];
-  const int b = blockIdx.x / G, g = blockIdx.x % G, cg = C / G;
+// ---- GroupNorm over NHWC (+ optional residual add and ReLU) ---------------------------------------------------------
+// Statistics: grid (splits, B*G) - workgroup (s, bg) accumulates sum and sum of squares (fp64) over its slice of the
+// group's pixels (float4 loads of the group's contiguous channels) -> part[bg][s][2]; the apply kernel (same grid) first
+// combines the `splits` partials in fixed order, then normalises its slice.  Two passes over the data instead of three,
+// and enough workgroups to fill the chip when B*G is small (B = 1: 32 groups).
+template <int VEC>
+__global__ void __launch_bounds__(256) groupnorm_stats_kernel(const float* __restrict__ x, long long HW, int C, int G,
+                                                               double* __restrict__ part) {
+  __shared__ double red[2][4];
+  const int bg = blockIdx.y, b = bg / G, g = bg % G, cg = C / G, v4 = cg / VEC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long base = (long long)b * HW * C + (long long)g * cg;
-  const long long n = HW * cg;
-  double s = 0.0;
-  for (long long i = tid; i < n; i += 256) s += x[base + (i / cg) * C + (i % cg)];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) red[wv] = s;
-  __syncthreads();
-  const float mean = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
-  __syncthreads();
-  double v = 0.0;
-  for (long long i = tid; i < n; i += 256) {
-    const float d = x[base + (i / cg) * C + (i % cg)] - mean;
-    v += (double)d * d;
+  const long long per = (HW + gridDim.x - 1) / gridDim.x;
+  const long long p0 = (long long)blockIdx.x * per, p1 = min(HW, p0 + per);
+  const float* base = x + (long long)b * HW * C + (long long)g * cg;
+  double s = 0.0, s2 = 0.0;
+  const long long n4 = (p1 - p0) * v4;
+  for (long long i = tid; i < n4; i += 256) {
+    const long long pix = p0 + i / v4;
+    const float* px = base + pix * C + (i % v4) * VEC;
+    if constexpr (VEC == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(px);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      const double v = px[0];
+      s += v; s2 += v * v;
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  if (lane == 0) red[wv] = v;
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (lane == 0) { red[0][wv] = s; red[1][wv] = s2; }
   __syncthreads();
-  if (tid == 0) { stat[0] = mean; stat[1] = (float)(1.0 / sqrt(((red[0] + red[1]) + (red[2] + red[3])) / (double)n + (double)eps)); }
-  __syncthreads();
-  const float rstd = stat[1];
-  for (long long i = tid; i < n; i += 256) {
-    const int c = (int)(i % cg);
-    const long long o = base + (i / cg) * C + c;
-    float y = (x[o] - mean) * rstd * gamma[g * cg + c] + beta[g * cg + c];
-    if (residual) y += residual[o];
-    if (relu) y = fmaxf(y, 0.f);
-    out[o] = y;
+  if (tid == 0) {
+    double* o = part + ((long long)bg * gridDim.x + blockIdx.x) * 2;
+    o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const float* __restrict__ x, long long HW, int C, int G,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               const float* __restrict__ residual, int relu,
+                                                               const double* __restrict__ part, float* __restrict__ out) {
+  const int bg = blockIdx.y, b = bg / G, g = bg % G, cg = C / G, v4 = cg / VEC;
+  const int tid = threadIdx.x;
+  double s = 0.0, s2 = 0.0;
+  for (int i = 0; i < (int)gridDim.x; ++i) { s += part[((long long)bg * gridDim.x + i) * 2]; s2 += part[((long long)bg * gridDim.x + i) * 2 + 1]; }
+  const double n = (double)HW * cg;
+  const double mean_d = s / n;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(fmax(s2 / n - mean_d * mean_d, 0.0) + (double)eps));
+  const long long per = (HW + gridDim.x - 1) / gridDim.x;
+  const long long p0 = (long long)blockIdx.x * per, p1 = min(HW, p0 + per);
+  const long long goff = (long long)b * HW * C + (long long)g * cg;
+  const long long n4 = (p1 - p0) * v4;
+  for (long long i = tid; i < n4; i += 256) {
+    const int c4 = (int)(i % v4) * VEC;
+    const long long o = goff + (p0 + i / v4) * C + c4;
+    if constexpr (VEC == 1) {
+      float y = (x[o] - mean) * rstd * gamma[g * cg + c4] + beta[g * cg + c4];
+      if (residual) y += residual[o];
+      if (relu) y = fmaxf(y, 0.f);
+      out[o] = y;
+      continue;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cg + c4), be = *reinterpret_cast<const float4*>(beta + g * cg + c4);
+    float4 y;
+    y.x = (v.x - mean) * rstd * ga.x + be.x; y.y = (v.y - mean) * rstd * ga.y + be.y;
+    y.z = (v.z - mean) * rstd * ga.z + be.z; y.w = (v.w - mean) * rstd * ga.w + be.w;
+    if (residual) { const float4 r = *reinterpret_cast<const float4*>(residual + o); y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
+    if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    *reinterpret_cast<float4*>(out + o) = y;
   }
 }
 
@@ -309,11 +343,25 @@ int dic_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stri
   return bn_relu_maxpool(x, B, H, W, C, nullptr, 0, k, stride, 0, out, nullptr, (hipStream_t)stream, nullptr);
 }
 
+size_t dic_groupnorm_workspace_bytes(int B, int groups) { return (size_t)B * groups * 64 * 2 * sizeof(double); }
+
 int dic_groupnorm_nhwc(const float* x, int B, long long HW, int C, int groups, const float* gamma, const float* beta,
-                       float eps, const float* residual, int relu, float* out, void* stream) {
-  DIC_REQUIRE(x && out && gamma && beta && B > 0 && HW > 0 && groups > 0 && C % groups == 0, "groupnorm_nhwc: bad arguments");
-  hipLaunchKernelGGL(groupnorm_nhwc_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, HW, C, groups, gamma, beta,
-                     eps, residual, relu, out);
+                       float eps, const float* residual, int relu, float* out, void* workspace, void* stream) {
+  DIC_REQUIRE(x && out && gamma && beta && workspace && B > 0 && HW > 0 && groups > 0 && C % groups == 0,
+              "groupnorm_nhwc: bad arguments");
+  // enough pixel slices for >= ~1024 workgroups, at most 64, at least 256 pixels per slice
+  int splits = (int)std::min<long long>(64, std::max<long long>(1, std::min<long long>(1024 / std::max(1, B * groups), HW / 256)));
+  if ((C / groups) % 4 == 0) {
+    hipLaunchKernelGGL(groupnorm_stats_kernel<4>, dim3(splits, B * groups), dim3(256), 0, (hipStream_t)stream, x, HW, C, groups,
+                       (double*)workspace);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<4>, dim3(splits, B * groups), dim3(256), 0, (hipStream_t)stream, x, HW, C, groups,
+                       gamma, beta, eps, residual, relu, (const double*)workspace, out);
+  } else {       // (the 64-channel stem: 2 channels per group)
+    hipLaunchKernelGGL(groupnorm_stats_kernel<1>, dim3(splits, B * groups), dim3(256), 0, (hipStream_t)stream, x, HW, C, groups,
+                       (double*)workspace);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<1>, dim3(splits, B * groups), dim3(256), 0, (hipStream_t)stream, x, HW, C, groups,
+                       gamma, beta, eps, residual, relu, (const double*)workspace, out);
+  }
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -63,6 +63,7 @@ class DptRunner:
                 w = wo
             self.conv_w[key] = w
         self.pos_cache: Dict[tuple, torch.Tensor] = {}
+        self.gn_ws: Optional[torch.Tensor] = None
 
     # ---- operator wrappers ----------------------------------------------------------------------
     def _new(self, *shape) -> torch.Tensor:
@@ -99,9 +100,13 @@ class DptRunner:
         """[timm] GroupNormAct(32, eps 1e-5) [+ residual] [+ ReLU]."""
         B, H, W, Cc = x.shape
         y = torch.empty_like(x)
+        self.lib.dic_groupnorm_workspace_bytes.restype = C.c_size_t
+        need = self.lib.dic_groupnorm_workspace_bytes(B, 32)
+        if self.gn_ws is None or self.gn_ws.numel() < need:
+            self.gn_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         check(self.lib.dic_groupnorm_nhwc(ptr(x), B, C.c_longlong(H * W), Cc, 32, ptr(self.w[prefix + "weight"]),
                                           ptr(self.w[prefix + "bias"]), C.c_float(1e-5), ptr(residual), 1 if relu else 0, ptr(y),
-                                          stream_ptr()), "dic_groupnorm_nhwc")
+                                          ptr(self.gn_ws), stream_ptr()), "dic_groupnorm_nhwc")
         return y
 
     def layer_norm(self, x: torch.Tensor, prefix: str) -> torch.Tensor:

@@ -272,9 +272,11 @@ int dic_pad_nhwc(const float* x, int B, int H, int W, int C, int top, int left, 
                  float* out, void* stream);
 /* nn.MaxPool2d(k, stride), no padding (pad first with -inf for 'SAME'), NHWC, C % 4 == 0 */
 int dic_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, float* out, void* stream);
-/* GroupNormAct: out = [relu]( GroupNorm(groups, C, eps)(x) [+ residual] ), x / residual / out [B, HW, C] */
+/* GroupNormAct: out = [relu]( GroupNorm(groups, C, eps)(x) [+ residual] ), x / residual / out [B, HW, C];
+ * workspace: dic_groupnorm_workspace_bytes(B, groups) of device scratch (per-slice fp64 partial sums) */
+size_t dic_groupnorm_workspace_bytes(int B, int groups);
 int dic_groupnorm_nhwc(const float* x, int B, long long HW, int C, int groups, const float* gamma, const float* beta,
-                       float eps, const float* residual, int relu, float* out, void* stream);
+                       float eps, const float* residual, int relu, float* out, void* workspace, void* stream);
 /* nn.LayerNorm(C, eps) over [rows, C] */
 int dic_layernorm(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* out,
                   void* stream);
