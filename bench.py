@@ -11,8 +11,10 @@ already resident in HBM: ResNet-152 forward (batch-statistics BN, quirk Q1) -> d
 decoder forward (T=20) -> CE + attention regulariser -> BPTT backward -> depth-encoder backward ->
 gradient all-reduce (N>1) -> AdamW.  Nothing is skipped inside the timed region.  The frozen ResNet forward of
 batch i+1 runs on a side HIP stream concurrently with the rest of step i (it takes no gradient and is not touched
-by the optimiser, so this is pure software pipelining: K timed steps still contain K ResNet forwards and the
-closing synchronize waits for both streams; --no-overlap disables it).  Weak scaling: every rank
+by the optimiser, so this is pure software pipelining: K timed steps still contain K ResNet forwards - the ones launched
+in the last two timed steps belong to batches after the timed region, exactly as many as the warm-up's last steps
+contributed to the first timed steps - and the closing synchronize waits for every stream; since round 2 the forwards of
+the next TWO batches are in flight on two side streams (--prefetch-depth 1 = one; --no-overlap disables it).  Weak scaling: every rank
 processes --batch images per step (default 64 = BASELINE.json configs[1]); value = N*batch*K / max-rank time.
 
 The JSON line also carries
@@ -285,6 +287,8 @@ def main():
                     help="separate workload (never mixed into the headline): forward of the frozen DPT-Hybrid depth "
                          "front-end of BASELINE config 5 at 384x384 + standardise + resize to 224 (depth_train.py:185-190)")
     ap.add_argument("--dpt-batch", type=int, default=8)
+    ap.add_argument("--prefetch-depth", type=int, default=2, choices=[1, 2],
+                    help="frozen-ResNet forwards of upcoming batches in flight on side streams (1 = round-1 behaviour)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
@@ -323,6 +327,9 @@ def main():
     from depth_image_captioning_pub_amd import synthetic as syn
     from depth_image_captioning_pub_amd.engine import CaptionTrainer
 
+    if os.environ.get("DIC_DEBUG_SWITCHES"):          # development only: comma-separated dic_debug_force_staged_gemm codes
+        for code in os.environ["DIC_DEBUG_SWITCHES"].split(","):
+            _lib.load().dic_debug_force_staged_gemm(int(code))
     if args.dpt:
         return bench_dpt(args, dev, world, rank)
     B = args.batch
@@ -334,7 +341,8 @@ def main():
     caps, lens = syn.captions_fixed(B, VOCAB, SEQ_LEN, seed=123 + rank)
     caps = caps.to(dev)
     step_args = (imgs, depth, caps, lens)
-    pipe = {} if args.no_overlap else {"next_imgs": imgs}   # software-pipeline the frozen ResNet across steps
+    # software-pipeline the frozen ResNet across steps: the forwards of the next two batches run ahead on two side streams
+    pipe = {} if args.no_overlap else {"next_imgs": [imgs] * args.prefetch_depth}
 
     def sync():
         if world > 1:
@@ -438,7 +446,8 @@ def main():
                                    f"V={VOCAB}, ResNet-152 (random init, batch-stat BN) + depth CNN + soft-attention LSTM",
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": SEQ_LEN, "vocab": VOCAB,
                        "parallelism": f"dp{world}", "resnet_conv_mode": args.conv_mode,
-                       "cross_step_resnet_overlap": not args.no_overlap, "annotation_cells": cells},
+                       "cross_step_resnet_overlap": not args.no_overlap,
+                       "resnet_forwards_in_flight": 0 if args.no_overlap else args.prefetch_depth, "annotation_cells": cells},
             "loss": round(loss_val, 5), "stages_ms": stages,
             "stages_note": "one extra un-overlapped step after the timed region: every stage on the main stream, incl. "
                            "the ResNet-152 forward that the timed steps run on the side stream",

@@ -99,14 +99,29 @@ def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None
             temp = temp_anneal(epoch)
         window, losses = deque(), []
         # with the DPT front-end the "dataset" is the same every epoch (that is what makes the depth cache meaningful)
-        for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank, config.iters_per_epoch,
-                                                                          0 if use_dpt else 1000 * epoch, raw=use_dpt)):
-            if use_dpt:
-                imgs, depth = front.depth_maps(epoch, [f"{it}:{i}" for i in range(len(lens))], imgs.to(dev))
+        def on_device():
+            """Batches of the epoch on the device (with the DPT front-end: normalised + depth maps from prediction / cache)."""
+            for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank, config.iters_per_epoch,
+                                                                              0 if use_dpt else 1000 * epoch, raw=use_dpt)):
+                if use_dpt:
+                    imgs, depth = front.depth_maps(epoch, [f"{it}:{i}" for i in range(len(lens))], imgs.to(dev))
+                yield it, imgs.to(dev), depth.to(dev), caps.to(dev), lens
+        # two batches of look-ahead: the frozen RGB encoder runs ahead of the step on side streams (engine.prefetch_features)
+        ahead, stream_it = [], on_device()
+        for nxt in stream_it:
+            ahead.append(nxt)
+            if len(ahead) > 2:
+                break
+        while ahead:
+            it, imgs, depth, caps, lens = ahead.pop(0)
+            nxt = next(stream_it, None)
+            if nxt is not None:
+                ahead.append(nxt)
             # the reference draws a fresh torch.rand(bs, 196) per decode step of every iteration (attention.py:17); here
             # the T draws of one iteration come as one [T,B,196] tensor from a stream keyed by (epoch, iteration, rank)
             u = _gumbel_draws(max(lens) - 1, len(lens), epoch, it, rank, int(ext)).to(dev) if hard else None
-            loss = trainer.train_step(imgs.to(dev), depth.to(dev), caps.to(dev), lens, gumbel_u=u, temp=float(temp))
+            loss = trainer.train_step(imgs, depth, caps, lens, gumbel_u=u, temp=float(temp),
+                                      next_imgs=[a[1] for a in ahead[:2]])
             losses.append(loss)                                         # device tensors: no per-iteration host sync
             window.append(loss)
             if len(window) > config.moving_avg:

@@ -7,6 +7,7 @@ using namespace dic;
 namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); void decoder_debug_persistent(int on);
                 void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p); }
 
+
 extern "C" {
 
 int dic_version(void) { return 100; }
@@ -43,11 +44,24 @@ int dic_debug_force_staged_gemm(int on) {
   if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
   if (on == 11 || on == 21 || on == 22 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 52) || (on >= 60 && on <= 63)) gemm_bf3_force_tile(on == 20 ? 0 : on);
-  else gemm_force_v1(on);
+  else if (on >= 0 && on <= 13) gemm_force_v1(on);
+  else DIC_REQUIRE(false, "debug switch: unknown code");
   return 0;
 }
 /* development aid (not in dic.h): device buffer [T][8] receiving phase time stamps of the persistent decoder loop */
 int dic_debug_decoder_stamps(unsigned long long* dev_buf) { dic::decoder_persist_debug_buffer(dev_buf); return 0; }
+/* development aid (not in dic.h): depth-encoder layer-1 kernels alone (csrc/conv1_depth.hip); y [B,OH,OW,128]; ws >= 1024 * 6400 floats */
+int dic_debug_conv1_wgrad(const float* x, int B, int H, int W, const float* dy, float* dw, float* dbias, float* ws, float* cs_ws,
+                          void* stream) {
+  ConvDesc d{B, H, W, 1, 128, 7, 7, 3, 0, 0};
+  return conv1_depth_wgrad(x, d, dy, dw, dbias, ws, cs_ws, (hipStream_t)stream);
+}
+int dic_debug_conv1_fwd(const float* x, int B, int H, int W, const float* w, const float* bias, float* y, float* partial,
+                        void* stream) {
+  ConvDesc d{B, H, W, 1, 128, 7, 7, 3, 0, 0};
+  int rows = 0;
+  return conv1_depth_fwd(x, d, w, bias, y, partial, &rows, (hipStream_t)stream);
+}
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
   DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");

@@ -10,6 +10,15 @@
 //     the weight gradient keeps 49 float2 accumulators.
 // Both are bound by the 128-channel fp32 activation stream (write of y / read of dy: 179 MB at batch 64).
 // Exact fp32 FMA arithmetic; summation order per output differs from the MFMA kernel only in the usual fp32 round-off.
+//
+// OFF BY DEFAULT since round 2 (debug codes 131..134 switch it on).  Alone on the chip both kernels are bit-reproducible,
+// but while the bf16x3 ResNet forward of the next batch runs on a second stream (engine.py, two forwards in flight) one
+// pixel in ~10^5 comes out with channels 48..63 (the x half of lanes 48..63, i.e. the last of the four 16-lane passes of
+// one packed FMA) off by up to 0.1 - in registers, the BatchNorm partial sums see it too.  Excluded so far: LDS written
+// by another workgroup (scripts/diag_lds_canary.py), the row ring (extra barriers, vmcnt(0) waits, static LDS: no change);
+// claiming the CU's whole LDS (one wave per SIMD) hides it, and so does any edit that shifts the instruction schedule
+// (scripts/diag_conv1_race.py).  Until that is understood the generic gather kernels carry layer 1: they were
+// bit-identical over every overlapped repetition, and the overlapped step costs the same with either (15.8 ms).
 #include "conv.h"
 #include "nn_kernels.h"
 
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(256, 3) conv1_wgrad_kernel(const float* __rest
 }
 
 static int g_c1_blocks = 512;     // persistent workgroups (<= 512 keeps the BatchNorm finalize a single launch)
-static int g_c1_on = 1;            // benchmarking / debugging (code 130): 0 = generic MFMA gather path instead
+static int g_c1_on = 0;            // see the note at the top; debug codes 131..134 = on with 256..1024 workgroups, 130 = off
 void conv1_depth_debug_blocks(int n) { if (n <= 0) { g_c1_on = 0; return; } g_c1_on = 1; g_c1_blocks = n > 1024 ? 1024 : n; }
 bool conv1_depth_enabled() { return g_c1_on != 0; }
 

@@ -71,6 +71,12 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < row4; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 
+__global__ void __launch_bounds__(256) bn_ema_update_kernel(float* __restrict__ running, const float* __restrict__ delta,
+                                                             long long n, float keep) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) running[i] = keep * running[i] + delta[i];
+}
+
 }  // namespace dic
 
 using namespace dic;
@@ -118,6 +124,19 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
   const int bx = (int)((row4 + 255) / 256 < 64 ? (row4 + 255) / 256 : 64);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, table, (const long long*)idx, row4,
                      out);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+/* running[i] = (1 - momentum) * running[i] + delta[i]: the BatchNorm running-statistics update of ONE batch applied after the
+ * fact.  A frozen-encoder forward that runs ahead on a side stream (engine.prefetch_features) is given zeroed scratch buffers
+ * in place of running_mean / running_var, so its finalize kernels leave delta = momentum * batch statistic there; the
+ * trainer applies the deltas on the main stream in the order the batches are consumed, which keeps the running statistics
+ * in batch order (quirk Q1, depth_train.py:161) however many forwards are in flight. */
+int dic_bn_ema_update(float* running, const float* delta, long long n, float momentum, void* stream) {
+  DIC_REQUIRE(running && delta && n > 0 && momentum >= 0.f && momentum <= 1.f, "bn_ema_update: bad arguments");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(bn_ema_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, running, delta, n, 1.0f - momentum);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -95,6 +95,73 @@ def exchange_gradients(flat_grad: torch.Tensor, spans, group, between=None) -> N
         w.wait()
 
 
+class _PrefetchSlot:
+    """One frozen-ResNet forward in flight: own HIP stream, own runner (shared weights, own workspace, BatchNorm
+    running-statistic pointers redirected to `delta`), own feature buffer, static input buffer and captured graphs."""
+
+    def __init__(self, tr: "CaptionTrainer"):
+        self.tr = tr
+        self.stream = torch.cuda.Stream(device=tr.device)
+        self.delta = torch.zeros_like(tr.rn_stats)            # momentum * batch statistic of the forward in flight
+        views, o = {}, 0
+        for k in tr.rn_stat_keys:
+            n = tr.rn_w[k].numel()
+            views[k] = self.delta[o:o + n]
+            o += n
+        self.runner = tr.resnet.shadow(views)
+        self.feat: Optional[torch.Tensor] = None
+        self.rn_in: Optional[torch.Tensor] = None
+        self.graphs = {}                                     # (shape, compact, workspace ptr) -> CUDAGraph
+
+    def _forward(self, x, compact):
+        self.delta.zero_()       # the finalize kernels then leave (1 - m) * 0 + m * stat = m * stat here
+        self.runner.forward(x, train_bn=True, out=self.feat, compact=compact)
+
+    def launch(self, imgs: torch.Tensor, compact: bool):
+        tr = self.tr
+        B = imgs.shape[0]
+        cells = native.L_COMPACT if compact else native.L_CELLS
+        if self.feat is None or tuple(self.feat.shape[:2]) != (B, cells):
+            self.feat = torch.empty((B, cells, native.D_ENC), dtype=torch.float32, device=tr.device)
+            self.graphs = {}                                 # captured with the old buffer
+        ready = torch.cuda.Event()
+        ready.record()                                       # inputs + previous readers of this slot's buffers are done
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            if not tr.use_graph:
+                self._forward(imgs, compact)
+            else:
+                if self.rn_in is None or self.rn_in.shape != imgs.shape:
+                    self.rn_in = torch.empty_like(imgs, memory_format=torch.contiguous_format)
+                    self.graphs = {}
+                self.rn_in.copy_(imgs, non_blocking=True)
+                ws = self.runner.workspace
+                # a graph holds raw pointers: it is only valid for the workspace it was captured with
+                key = (tuple(imgs.shape), compact, ws.data_ptr() if ws is not None else 0)
+                g = self.graphs.get(key)
+                if g is None:
+                    # first use: one eager forward (sizes the workspace, and is this batch's forward), then capture the same
+                    # calls for the following batches (capturing records the launches, it does not run them)
+                    self._forward(self.rn_in, compact)
+                    self.stream.synchronize()
+                    key = key[:2] + (self.runner.workspace.data_ptr(),)
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        # thread_local: other threads (e.g. the RCCL watchdog) may keep issuing their own HIP calls
+                        with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                            self._forward(self.rn_in, compact)
+                        self.graphs = {key: g}
+                    except Exception as exc:      # capture unsupported here: stay on eager launches (same results)
+                        tr.use_graph = False
+                        self.graphs = {}
+                        tr.last["resnet_graph_error"] = repr(exc)
+                else:
+                    g.replay()
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return done
+
+
 class CaptionTrainer:
     """Owns weights, optimiser state and workspaces of one rank and runs fused train steps."""
 
@@ -129,6 +196,15 @@ class CaptionTrainer:
         self.enc_span = self.flat.span(["depth_encoder." + k for k in self.enc_names])
         self.enc_state = {k: v.to(self.device).contiguous() for k, v in depth_state.items()}
         self.rn_w = {k: v.to(self.device).contiguous() for k, v in rn.items()}
+        # every BatchNorm running statistic of the frozen ResNet lives in ONE flat buffer (the dict holds views), so that
+        # the update of a whole batch is one dic_bn_ema_update launch (see _PrefetchSlot)
+        self.rn_stat_keys = [k for k in self.rn_w if k.endswith("running_mean") or k.endswith("running_var")]
+        self.rn_stats = torch.cat([self.rn_w[k].reshape(-1) for k in self.rn_stat_keys]).contiguous()
+        o = 0
+        for k in self.rn_stat_keys:
+            n = self.rn_w[k].numel()
+            self.rn_w[k] = self.rn_stats[o:o + n]
+            o += n
         self.resnet = native.ResNetRunner(self.rn_w, resnet_layers, conv_mode=conv_mode)
         self.step_count = 0
         self.depth_fwd_count = 0       # train-mode depth-encoder forwards (= BatchNorm num_batches_tracked)
@@ -140,23 +216,23 @@ class CaptionTrainer:
         self.dec_ws: Optional[torch.Tensor] = None
         self.enc_ws: Optional[torch.Tensor] = None
         self.last = {}
-        # software pipelining of the frozen RGB encoder: features of the NEXT batch are computed on a side
-        # stream while the rest of the current step runs (see prefetch_features)
-        self.side_stream = torch.cuda.Stream(device=self.device)
-        self.feat_bufs = [None, None]
-        self.feat_flip = 0
-        self.prefetched = None         # (imgs tensor, features, done-event)
-        self.side_done = None          # completion event of the newest side-stream ResNet forward (see _resnet_eager)
-        # the prefetched forward is ~620 launches (9 ms of host enqueue per step); it is captured once per
-        # (batch shape, output buffer) into a hipGraph and replayed (0.2 ms), so the main stream's work is enqueued
-        # right away instead of 9 ms into the step.  DIC_RESNET_GRAPH=0 keeps eager launches.
+        # Software pipelining of the frozen RGB encoder: the features of the NEXT batches are computed on side streams while
+        # the rest of the current step runs (prefetch_features).  Up to `prefetch_depth` forwards are in flight, each on its own
+        # stream with its own workspace (_PrefetchSlot): two concurrent forwards fill each other's dependent-launch gaps and
+        # shallow-grid idle CUs - 25.5 ms for two batch-64 forwards against 29.6 ms back to back (scripts/bench_resnet_concurrent.py).
+        self.prefetch_depth = int(os.environ.get("DIC_PREFETCH_DEPTH", "2"))
+        self.slots: List[_PrefetchSlot] = []
+        self.slot_next = 0
+        self.queue: List[tuple] = []   # FIFO of (imgs tensor, slot, done-event) in launch (= batch) order
+        self.side_done = None          # completion event of the newest side-stream forward (see _resnet_eager)
+        self.feat_copy: Optional[torch.Tensor] = None
+        # each forward is ~620 launches (9 ms of host enqueue); it is captured once per (batch shape, slot) into a hipGraph
+        # and replayed (0.2 ms).  DIC_RESNET_GRAPH=0 keeps eager launches.
         self.use_graph = os.environ.get("DIC_RESNET_GRAPH", "1") != "0"
         # compact 49-cell layout (quirk Q3): at 224x224 both encoders end in a 7x7 map that AdaptiveAvgPool2d(14) only
         # replicates 2x2, so the soft-attention decoder runs on the 49 distinct cells (same logits / alphas / gradients,
         # 4x less feature traffic).  DIC_COMPACT_CELLS=0 keeps the reference's 196-cell evaluation everywhere.
         self.compact_ok = os.environ.get("DIC_COMPACT_CELLS", "1") != "0"
-        self.rn_in: Optional[torch.Tensor] = None      # static input of the captured graphs
-        self.rn_graphs = {}                            # (shape, buffer index) -> torch.cuda.CUDAGraph
         self.keep_outputs = False      # True: keep logits intact (loss gradient not written in place)
         self.timing = False            # True: record stage-boundary events on the current stream
         self.marks = []
@@ -174,66 +250,65 @@ class CaptionTrainer:
             out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
         return out
 
+    @property
+    def prefetched(self):
+        """Oldest pending prefetch as (imgs, features, done-event), or None (kept for tests / callers of round 1)."""
+        if not self.queue:
+            return None
+        imgs, slot, done = self.queue[0]
+        return imgs, slot.feat, done
+
+    @prefetched.setter
+    def prefetched(self, value):
+        if value is not None:
+            raise DicError("only `prefetched = None` (drop every pending prefetch) is supported")
+        self.queue = []
+
+    @property
+    def rn_graphs(self):
+        return {(i,) + k: g for i, sl in enumerate(self.slots) for k, g in sl.graphs.items()}
+
     def prefetch_features(self, imgs: torch.Tensor, compact: bool = False) -> None:
-        """Launch the frozen ResNet-152 forward of an upcoming batch on the side stream.  Legal because the RGB
-        encoder takes no gradient and is not touched by the optimiser (depth_train.py:136): its output for batch
-        i+1 does not depend on the update of step i; its BatchNorm running statistics are still updated once per
-        batch, in batch order (all ResNet work is serialised on the one side stream)."""
-        B = imgs.shape[0]
-        i = self.feat_flip
-        self.feat_flip ^= 1
+        """Launch the frozen ResNet-152 forward of an upcoming batch on a side stream.  Legal because the RGB encoder takes
+        no gradient and is not touched by the optimiser (depth_train.py:136): its output for batch i+k does not depend on
+        the updates of steps i..i+k-1.  Its BatchNorm running statistics (quirk Q1) are still updated once per batch and
+        in batch order: the forward leaves momentum * (batch statistic) in the slot's scratch buffers, and train_step applies
+        it (dic_bn_ema_update) when it consumes the features - consumption order is batch order."""
+        if len(self.queue) >= self.prefetch_depth:
+            raise DicError(f"{len(self.queue)} prefetched batches are pending (prefetch_depth = {self.prefetch_depth}): "
+                           "consume one with train_step before prefetching more")
+        while len(self.slots) < self.prefetch_depth:
+            self.slots.append(_PrefetchSlot(self))
+        busy = {id(sl) for _, sl, _ in self.queue}
+        slot = next(sl for sl in self.slots[self.slot_next:] + self.slots[:self.slot_next] if id(sl) not in busy)
+        self.slot_next = (self.slots.index(slot) + 1) % len(self.slots)
         compact = compact and tuple(imgs.shape[-2:]) == (224, 224)
-        cells = native.L_COMPACT if compact else native.L_CELLS
-        if self.feat_bufs[i] is None or tuple(self.feat_bufs[i].shape[:2]) != (B, cells):
-            self.feat_bufs[i] = torch.empty((B, cells, native.D_ENC), dtype=torch.float32, device=self.device)
-            self.rn_graphs = {k: v for k, v in self.rn_graphs.items() if k[1] != i}      # captured with the old buffer
-        ready = torch.cuda.Event()
-        ready.record()                                   # inputs + previous readers of this buffer are done
-        with torch.cuda.stream(self.side_stream):
-            self.side_stream.wait_event(ready)
-            feats = self.feat_bufs[i]
-            if not self.use_graph:
-                self.resnet.forward(imgs, train_bn=True, out=feats, compact=compact)
-            else:
-                ws = self.resnet.workspace
-                # a graph holds raw pointers: it is only valid for the workspace it was captured with (an eager forward
-                # of a larger batch re-allocates it), so the workspace address is part of the key
-                key = (tuple(imgs.shape), i, compact, ws.data_ptr() if ws is not None else 0)
-                if self.rn_in is None or self.rn_in.shape != imgs.shape:
-                    self.rn_in = torch.empty_like(imgs, memory_format=torch.contiguous_format)
-                    self.rn_graphs = {}
-                self.rn_in.copy_(imgs, non_blocking=True)
-                g = self.rn_graphs.get(key)
-                if g is None:
-                    # first use: one eager forward (sizes the workspace, and is this batch's forward), then capture
-                    # the same call for the following batches (capturing records the launches, it does not run them,
-                    # so the BatchNorm running statistics still advance exactly once per batch)
-                    self.resnet.forward(self.rn_in, train_bn=True, out=feats, compact=compact)
-                    self.side_stream.synchronize()
-                    key = key[:3] + (self.resnet.workspace.data_ptr(),)      # (the eager call may have sized it)
-                    self.rn_graphs = {k: v for k, v in self.rn_graphs.items() if k[3] == key[3]}
-                    try:
-                        g = torch.cuda.CUDAGraph()
-                        # thread_local: other threads (e.g. the RCCL watchdog) may keep issuing their own HIP calls
-                        with torch.cuda.graph(g, stream=self.side_stream, capture_error_mode="thread_local"):
-                            self.resnet.forward(self.rn_in, train_bn=True, out=feats, compact=compact)
-                        self.rn_graphs[key] = g
-                    except Exception as exc:      # capture unsupported here: stay on eager launches (same results)
-                        self.use_graph = False
-                        self.rn_graphs = {}
-                        self.last["resnet_graph_error"] = repr(exc)
-                else:
-                    g.replay()
-                    self.resnet.train_forwards += 1
-            done = torch.cuda.Event()
-            done.record(self.side_stream)
-        self.prefetched = (imgs, feats, done)
+        done = slot.launch(imgs, compact)
+        self.queue.append((imgs, slot, done))
         self.side_done = done
 
+    def _take_prefetched(self, imgs: torch.Tensor):
+        """Features of `imgs` if its forward is the oldest one in flight: waits for it on the current stream and applies
+        its BatchNorm running-statistic update."""
+        if not self.queue or self.queue[0][0] is not imgs:
+            return None
+        _, slot, done = self.queue.pop(0)
+        torch.cuda.current_stream().wait_event(done)
+        native.bn_ema_update(self.rn_stats, slot.delta, 0.1)
+        self.resnet.train_forwards += 1
+        # the slot is free for the next prefetch from here on (train_step launches it before this step has read the
+        # features), so the step works on its own copy: one 26-MB device copy (~10 us), ordered on this stream before the
+        # `ready` event the slot's next forward waits for
+        if self.feat_copy is None or self.feat_copy.shape != slot.feat.shape:
+            self.feat_copy = torch.empty_like(slot.feat)
+        self.feat_copy.copy_(slot.feat, non_blocking=True)
+        return self.feat_copy
+
     def _resnet_eager(self, imgs: torch.Tensor, train_bn: bool, compact: bool) -> torch.Tensor:
-        """ResNet forward on the CURRENT stream.  The runner has one workspace and one set of BatchNorm running
-        statistics, shared with the side-stream prefetch: first wait for the newest side-stream forward (a later
-        prefetch waits for this call through its `ready` event), so the two never run concurrently."""
+        """ResNet forward on the CURRENT stream with the trainer's own runner (own workspace; BatchNorm running statistics
+        updated / read in place).  Ordered after the newest side-stream forward so that a validation pass or a step on an
+        un-prefetched batch never competes with a prefetch for the chip's memory system mid-kernel-chain; the pending
+        prefetches' running-statistic updates are applied later, when their batches are consumed."""
         if self.side_done is not None:
             torch.cuda.current_stream().wait_event(self.side_done)
         return self.resnet.forward(imgs, train_bn=train_bn, compact=compact)
@@ -256,10 +331,11 @@ class CaptionTrainer:
     def train_step(self, imgs: torch.Tensor, depth_map: torch.Tensor, captions: torch.Tensor, lengths: Sequence[int],
                    drop_mult: Optional[torch.Tensor] = None, gumbel_u: Optional[torch.Tensor] = None,
                    temp: float = 1.0, precomputed_features: Optional[torch.Tensor] = None,
-                   next_imgs: Optional[torch.Tensor] = None, global_tokens: Optional[int] = None,
+                   next_imgs=None, global_tokens: Optional[int] = None,
                    apply_update: bool = True, virtual_world: Optional[int] = None) -> torch.Tensor:
         """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync).
-        next_imgs: images of the following batch; their (frozen) ResNet forward is overlapped with this step.
+        next_imgs: images of the following batch, or the list [batch i+1, batch i+2, ...] of the next batches in order; their
+          (frozen) ResNet forwards run ahead on side streams, up to `prefetch_depth` (2) at a time.
         global_tokens: packed tokens (sum of lengths-1) of the GLOBAL batch when data parallel with variable-length
           captions; default = this rank's count x world size (exact for equal-length batches such as bench.py's).
         apply_update=False leaves the (scaled, all-reduced) gradients in self.flat.grad and skips AdamW;
@@ -271,15 +347,16 @@ class CaptionTrainer:
         self._mark("start")
         if precomputed_features is None:
             compact = self._compact(imgs, depth_map)
-            if self.prefetched is not None and self.prefetched[0] is imgs:
-                _, feats, done = self.prefetched
-                torch.cuda.current_stream().wait_event(done)
-                self.prefetched = None
+            feats = self._take_prefetched(imgs)
+            if feats is not None:
                 compact = feats.shape[1] == native.L_COMPACT
             else:
                 feats = self._resnet_eager(imgs, True, compact)                             # depth_train.py:179
-            if next_imgs is not None:
-                self.prefetch_features(next_imgs, compact=self._compact(next_imgs, depth_map))
+            if next_imgs is not None:       # one upcoming batch, or the list of the next `prefetch_depth` batches in order
+                upcoming = list(next_imgs) if isinstance(next_imgs, (list, tuple)) else [next_imgs]
+                for k, nxt in enumerate(upcoming[:self.prefetch_depth]):
+                    if k >= len(self.queue):        # (entry k of the queue is batch i+1+k when the caller keeps this order)
+                        self.prefetch_features(nxt, compact=self._compact(nxt, depth_map))
             self._mark("resnet152_fwd")
             fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
                                                        workspace=self.enc_ws, compact=compact)   # :204-206

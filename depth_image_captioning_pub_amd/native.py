@@ -203,6 +203,14 @@ def adamw_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor,
     check(rc, "dic_adamw_step")
 
 
+def bn_ema_update(running: torch.Tensor, delta: torch.Tensor, momentum: float = 0.1) -> None:
+    """dic_bn_ema_update: running = (1 - momentum) * running + delta (flat fp32 buffers of equal length)."""
+    if not (running.is_cuda and running.is_contiguous() and delta.is_contiguous() and running.numel() == delta.numel()):
+        raise _lib.DicError("bn_ema_update needs two contiguous GPU buffers of equal length")
+    check(_lib.load().dic_bn_ema_update(ptr(running), ptr(delta), C.c_longlong(running.numel()), C.c_float(momentum),
+                                        stream_ptr()), "dic_bn_ema_update")
+
+
 def dropout_mask(shape, p: float, seed: int, offset: int, device) -> torch.Tensor:
     lib = _lib.load()
     out = torch.empty(shape, dtype=torch.float32, device=device)
@@ -381,6 +389,26 @@ class ResNetRunner:
             self.keep.append(tens)
         self.workspace: Optional[torch.Tensor] = None
         self.train_forwards = 0          # train-mode forwards so far (BatchNorm num_batches_tracked, quirk Q1)
+
+    def shadow(self, stats: Dict[str, torch.Tensor]) -> "ResNetRunner":
+        """A second runner over the SAME frozen weights (tensors shared) with its own workspace and its own layer table whose
+        BatchNorm running-statistic pointers are `stats[<bn prefix>running_mean / running_var]` - used by the engine to run
+        several forwards ahead concurrently: each writes its running-statistic updates into its own zeroed scratch buffers
+        (dic_bn_ema_update applies them later, in batch order)."""
+        other = object.__new__(ResNetRunner)
+        other.mode, other.blocks, other.spec, other.n_layers = self.mode, self.blocks, self.spec, self.n_layers
+        other.table = (ConvBnLayer * self.n_layers)()
+        for i, (_key, bn, *_rest) in enumerate(self.spec):
+            other.table[i] = self.table[i]
+            for field, name in (("running_mean", "running_mean"), ("running_var", "running_var")):
+                t = stats[bn + name]
+                if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                    raise _lib.DicError(f"{bn + name} must be a contiguous fp32 GPU tensor")
+                setattr(other.table[i], field, t.data_ptr())
+        other.keep = [self.keep, list(stats.values())]
+        other.workspace = None
+        other.train_forwards = 0
+        return other
 
     def forward(self, imgs: torch.Tensor, train_bn: bool, out: Optional[torch.Tensor] = None,
                 compact: bool = False) -> torch.Tensor:

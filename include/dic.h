@@ -302,6 +302,10 @@ int dic_resize_bilinear(const float* in, int planes, int H, int W, int resize_sh
                         float* out, void* stream);
 /* in place: NaN -> 0.5, then per-image (x-min)/(max-min)   (DPT_model.py:50-59); depth: [B, hw]. */
 int dic_depth_standardize(float* depth, int B, long long hw, void* stream);
+/* running[i] = (1 - momentum) * running[i] + delta[i]: BatchNorm running-statistics update of one batch, applied after a
+ * forward that ran ahead with zeroed scratch buffers in the running_mean / running_var slots of its layer table (those then
+ * hold momentum * batch statistic); keeps the statistics in batch order with several forwards in flight (engine.py). */
+int dic_bn_ema_update(float* running, const float* delta, long long n, float momentum, void* stream);
 /* out[r,:] = table[idx[r],:] (rows of row_floats floats, % 4 == 0; idx int64 on device): depth cache lookup. */
 int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row_floats, float* out, void* stream);
 
@@ -318,7 +322,9 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
  *   140 141      decoder forward loop: one launch pair per step (default) / one persistent launch for all steps
  *   142 143      persistent loop placement: a row group's 16 chunk workgroups on one XCD (default) / chunks 2x, 2x+1 on XCD x
- *   130..134     depth-encoder layer 1: generic MFMA gather path / packed-FMA kernels with 256, 512 (default), 768, 1024 workgroups
+ *   130..134     depth-encoder layer 1: generic MFMA gather path (default) / packed-FMA kernels with 256, 512, 768, 1024 workgroups
+ *                (off by default: not bit-reproducible next to a concurrent bf16x3 forward, see csrc/conv1_depth.hip)
+ * Unknown codes are rejected (DIC_ERR_ARG).
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + 2*(tile_m/64 - 1) + (tile_n/64 - 1). */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);

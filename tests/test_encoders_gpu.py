@@ -129,8 +129,8 @@ def test_depth_encoder_bench_shape_with_fp64_decision_replay(lib, B):
 
 
 def test_depth_encoder_wide_map_uses_generic_layer1(lib):
-    """Maps wider than the 640-float rows the packed-FMA layer-1 kernels stage in LDS fall back to the generic gather
-    kernels (same results, same API): 52 x 700 map, non-square feature grid pooled to 14 x 14."""
+    """A wide, flat map (52 x 700; wider than the 640-float rows the opt-in packed-FMA layer-1 kernels could stage) on the
+    generic gather kernels: non-square feature grid pooled to 14 x 14."""
     w, st = syn.depth_encoder_weights(seed=61)
     g = torch.Generator().manual_seed(61)
     depth = torch.rand((1, 1, 52, 700), generator=g)

@@ -191,6 +191,61 @@ def test_data_parallel_token_weighted_decomposition_ragged(lib):
     assert float((gw0[k] + gw1[k] - g_full[k]).abs().max()) > 1e-3 * float(g_full[k].abs().max())
 
 
+def test_two_forwards_in_flight_equal_sequential_forwards(lib):
+    """prefetch_depth 2: the forwards of batches i+1 and i+2 run concurrently on two streams with their own workspaces and
+    leave their BatchNorm running-statistic updates in scratch buffers that train_step applies in consumption (= batch)
+    order.  Features must be bit-identical to one-at-a-time eager forwards, and the running statistics must equal the
+    in-order in-place updates (same two products and one add per element; the summation may be contracted differently,
+    hence 1e-6)."""
+    B, size = 2, 64
+    batches = [syn.rgb_images(B, seed=180 + i, size=size).to(DEV) for i in range(6)]
+    tr = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode="bf16x3")
+    ref = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode="bf16x3")
+    tr.prefetch_features(batches[0])
+    for i, x in enumerate(batches):
+        if i + 1 < len(batches):
+            tr.prefetch_features(batches[i + 1])
+        assert len(tr.queue) <= 2
+        f = tr._take_prefetched(x)
+        f_ref = ref.resnet.forward(x, train_bn=True)           # eager, in place, in order
+        torch.cuda.synchronize()
+        assert torch.equal(f, f_ref), f"batch {i}"
+    for k in tr.rn_stat_keys:
+        _close(k, tr.rn_w[k], ref.rn_w[k], 1e-6, 1e-9)
+    with pytest.raises(Exception, match="pending"):            # a third forward in flight is refused, not silently dropped
+        tr.prefetch_features(batches[0]); tr.prefetch_features(batches[1]); tr.prefetch_features(batches[2])
+
+
+def test_overlapped_step_is_bit_reproducible_at_bench_shape(lib):
+    """Bench shape (64 x 224 x 224, vocabulary 10000, T = 20): the gradient computation of a step is repeated on fixed
+    weights while bf16x3 ResNet forwards of the next batches run on the two prefetch streams.  Loss, every gradient and the
+    prefetched features must be bit-identical in every repetition: kernels sharing CUs with another stream's kernels is the
+    normal operating condition of the pipelined step (the packed-FMA layer-1 kernels of round 1 failed exactly this, see
+    csrc/conv1_depth.hip; they are off by default)."""
+    B, V, T = 64, 10000, 20
+    tr = CaptionTrainer(V, device=DEV, seed=123, resnet_layers=TINY, conv_mode="bf16x3")
+    imgs = syn.rgb_images(B, seed=123).to(DEV); depth = syn.depth_maps(B, seed=123).to(DEV)
+    caps, lens = syn.captions_fixed(B, V, T, seed=123); caps = caps.to(DEV)
+    drop = syn.dropout_multiplier(B, T, 0.5, seed=123).to(DEV)
+    feats0 = tr.resnet.forward(imgs, True, compact=tr.compact_ok).clone()
+    ref = None
+    for rep in range(12):
+        tr.prefetch_features(imgs, compact=tr.compact_ok); tr.prefetch_features(imgs, compact=tr.compact_ok)
+        loss = tr.train_step(None, depth, caps, lens, drop_mult=drop, precomputed_features=feats0, apply_update=False)
+        g = tr.flat.grad.clone()
+        f1 = tr._take_prefetched(imgs).clone(); f2 = tr._take_prefetched(imgs).clone()
+        torch.cuda.synchronize()
+        cur = (float(loss.item()), g, f1, f2)
+        if ref is None:
+            ref = cur
+            assert torch.equal(f1, feats0) and torch.equal(f2, feats0)
+            continue
+        assert cur[0] == ref[0], f"repetition {rep}: loss {cur[0]!r} vs {ref[0]!r}"
+        bad = [k for k in tr.flat.names if not torch.equal(tr.flat.view(g, k), tr.flat.view(ref[1], k))]
+        assert not bad, f"repetition {rep}: gradients differ in {bad}"
+        assert torch.equal(f1, ref[2]) and torch.equal(f2, ref[3]), f"repetition {rep}: prefetched features differ"
+
+
 def test_prefetch_is_ordered_with_eager_forwards(lib):
     """train_step(next_imgs=X) leaves a ResNet forward running on the side stream; eval_loss / a train_step on another
     batch then run an EAGER forward on the main stream through the same workspace and BatchNorm buffers.  The engine must
@@ -287,18 +342,20 @@ def test_prefetch_graph_replay_equals_eager(lib, conv_mode):
         tr = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode=conv_mode)
         tr.use_graph = use_graph
         feats = []
-        for x in batches:
-            tr.prefetch_features(x)
-            _, f, done = tr.prefetched
-            done.synchronize()
+        tr.prefetch_features(batches[0])                       # two forwards in flight from here on, on two slots
+        for i, x in enumerate(batches):
+            if i + 1 < len(batches):
+                tr.prefetch_features(batches[i + 1])
+            f = tr._take_prefetched(x)                         # waits + applies the batch's running-statistic update
+            assert f is not None
+            torch.cuda.synchronize()
             feats.append(f.clone())
-        torch.cuda.synchronize()
         stats = {k: v.clone() for k, v in tr.rn_w.items() if "running" in k}
         return feats, stats, tr
 
     f_g, s_g, tr_g = run(True)
     f_e, s_e, _ = run(False)
-    assert tr_g.use_graph and len(tr_g.rn_graphs) == 2, tr_g.last.get("resnet_graph_error")     # both buffers captured
+    assert tr_g.use_graph and len(tr_g.rn_graphs) == 2, tr_g.last.get("resnet_graph_error")     # both slots captured
     for i, (a, b) in enumerate(zip(f_g, f_e)):
         assert torch.equal(a, b), f"batch {i}"
     assert s_g.keys() == s_e.keys() and len(s_g) > 0
