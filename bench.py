@@ -287,7 +287,7 @@ def main():
                     help="separate workload (never mixed into the headline): forward of the frozen DPT-Hybrid depth "
                          "front-end of BASELINE config 5 at 384x384 + standardise + resize to 224 (depth_train.py:185-190)")
     ap.add_argument("--dpt-batch", type=int, default=8)
-    ap.add_argument("--prefetch-depth", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--prefetch-depth", type=int, default=2, choices=[1, 2, 3],
                     help="frozen-ResNet forwards of upcoming batches in flight on side streams (1 = round-1 behaviour)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)

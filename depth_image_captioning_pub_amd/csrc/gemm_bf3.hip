@@ -10,6 +10,7 @@
 #include "conv.h"
 #include "gemm_epilogue.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace dic {
@@ -341,6 +342,274 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
   gemm_epilogue<BM, BN>(p, acc, tm, tn, 0, reinterpret_cast<float*>(smem));
 }
 
+
+// Deep-pipelined variant (round 2): 128x128 workgroup tile, 4 waves of 64x64 (12 fragment reads per 24 MFMAs instead of 9
+// per 12 for the 128x64 tile: LDS bytes per MFMA cycle 1.12 -> 0.75), ONE workgroup = one wave per SIMD per CU with the
+// whole register file, so latency is hidden inside the wave instead of by co-resident workgroups:
+//   * fragment registers are double-buffered by k-step: while the 24 MFMAs of k-step s run, the 12 reads of the next
+//     k-step (of the next K tile, for s = 1) are in flight;
+//   * one raw barrier per K tile, in the middle of it: by then a wave has all fragments of the tile in registers
+//     (lgkmcnt(0)) and its share of the next tile's DMA - issued a whole tile earlier - has long landed (vmcnt(0)), so
+//     neither wait stalls in steady state; after the barrier the stage just read is re-filled with tile it+2;
+//   * DMA issue and fragment reads are placed textually inside the MFMA runs (MFMA issue leaves 7 of 8 slots free).
+// Same per-element summation order as gemm_bf3_kernel (K ascending, small products first): bit-identical results.
+template <int AK, int NST>
+__global__ void __launch_bounds__(256) gemm_bf3_pipe_kernel(const Bf3Params p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
+  __shared__ __align__(1024) unsigned short smem[NST * STAGE];     // 48 KB per stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nkt = (p.K + BK3 - 1) / BK3;
+  const int t = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+
+  Bf3Loader<AK, BM> la;
+  Bf3Loader<OPK_ROWK, BN> lbld;
+  la.init(p.A, tm * BM, p.M, p.K);
+  lbld.init(p.B, tn * BN, p.N, p.K);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s0 = 0; s0 < NST; ++s0)
+    if (s0 < nkt) { la.issue(s0 * BK3, smem + s0 * STAGE); lbld.issue(s0 * BK3, smem + s0 * STAGE + AOPER); }
+
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
+  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+
+  u32x4 fa[2][2][3], fb[2][2][3];          // [k-step buffer][tile][plane]
+#define DIC_PIPE_READ_A(KS_, SB_, I_)                                                                                \
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+      bf3_lds_read(fa[KS_][I_][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)((I_) * 32 * 64) + pos[KS_]);
+#define DIC_PIPE_READ_B(KS_, SB_, J_)                                                                                \
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+      bf3_lds_read(fb[KS_][J_][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)((J_) * 32 * 64) + pos[KS_]);
+#define DIC_PIPE_PIN(KS_)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
+#define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
+                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
+
+  // prologue: tile 0 landed (tile 1's 12 DMA instructions may stay in flight), k-step 0 fragments on their way
+  if (nkt >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (NST - 1)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
+
+  for (int it = 0; it < nkt; ++it) {
+    const int st = it % NST, stn = (it + 1) % NST;
+    const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
+    unsigned short* cur = smem + st * STAGE;
+    // ---- k-step 0: its fragments were requested one k-step ago; request k-step 1 of this tile
+    DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    DIC_PIPE_PIN(0)
+    __builtin_amdgcn_sched_barrier(0);
+    // small terms first: al*bh, ah*bl, am*bm, am*bh, ah*bm, ah*bh   (plane 0 = hi, 1 = mid, 2 = lo)
+    DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- middle of the tile: every read of this stage has returned, the next tile has landed
+    // (tiles it+2 .. it+NST-1 may stay in flight: 12 DMA instructions each, retired in order)
+    if (NST == 2 || it + NST - 1 >= nkt) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(12 * (NST - 2)) : "memory");
+    DIC_PIPE_PIN(1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- k-step 1, with the refill of this stage (tile it+2) and the next tile's k-step-0 reads in its shadow
+    DIC_PIPE_MFMA(1, 2, 0)
+    if (it + 1 < nkt) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
+    DIC_PIPE_MFMA(1, 0, 2)
+    if (it + NST < nkt) la.issue((it + NST) * BK3, cur);
+    DIC_PIPE_MFMA(1, 1, 1)
+    if (it + NST < nkt) lbld.issue((it + NST) * BK3, cur + AOPER);
+    DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef DIC_PIPE_READ_A
+#undef DIC_PIPE_READ_B
+#undef DIC_PIPE_PIN
+#undef DIC_PIPE_MFMA
+  __syncthreads();
+  gemm_epilogue<BM, BN>(p, acc, tm, tn, 0, reinterpret_cast<float*>(smem));
+}
+
+
+// Persistent form of the deep-pipelined kernel: one workgroup per CU walks the output tiles  xcd_remap(blockIdx.x + j*grid)
+// and treats their K tiles as ONE stream of slots through a 3-stage ring (144 KB), so that what a fresh workgroup pays per
+// output tile - launch, loader set-up, the first DMA round trip, the drain of its stores (4.8 us per 128x128 tile against
+// 0.7 us per K tile: 40 % of a K = 256 tile) - disappears into the stream.  What it cannot change is the steady state, and
+// that is set by operand intake, not by the matrix cores: 48 KB per K tile arrive at ~68 GB/s per CU (two slots in flight
+// over ~1.4 us of loaded L2/HBM latency; the same figure the hardware guide measures for an LDS-DMA ring), i.e. 0.72 us per
+// K tile against 0.64 us of MFMA work at full rate - every tile shape of this file ends at 0.33-0.46 of the bf16 peak for
+// that reason, and only fewer operand bytes per FLOP (larger tiles, operand reuse in LDS) can move it.
+//   * the prefetch position (tile pj, K tile pkt) runs three slots ahead of the compute position and crosses tile seams;
+//     the loader state belongs to the prefetch side only and is re-derived in the MFMA shadow when it crosses;
+//   * at a seam the 64 stores of the tile go out straight from the accumulators; they sit in the vector-memory queue
+//     behind the DMA of the next two slots that is already in flight, and the counted wait of the two slots after a seam
+//     is vmcnt(63): at least 63 younger operations (64 stores + 12 DMA instructions) exist in issue order, so "at most 63
+//     outstanding" already guarantees the slot that is needed without waiting for any store's acknowledgement;
+//     masked edge tiles (whose stores may be skipped) fall back to the plain count, which only waits for more;
+//   * BatchNorm partial sums are written per 64-row wave tile ([2*mtiles][2][N]: no LDS exchange, no extra barrier).
+// Requires: plain store epilogue without bias (the ResNet convolutions), K >= 64.  Bit-identical to gemm_bf3_kernel.
+template <int AK>
+__global__ void __launch_bounds__(256) gemm_bf3_persist_kernel(const Bf3Params p) {
+  constexpr int BM = 128, BN = 128, NST = 3;
+  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
+  __shared__ __align__(1024) unsigned short smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nkt = (p.K + BK3 - 1) / BK3;
+  const int T = p.mtiles * p.ntiles, G = gridDim.x;
+  const int ntl = (T - (int)blockIdx.x + G - 1) / G;            // tiles of this workgroup
+  const int total = ntl * nkt;                                    // slots
+
+  Bf3Loader<AK, BM> la;
+  Bf3Loader<OPK_ROWK, BN> lbld;
+  int pj = 0, pkt = 0;                                            // prefetch position
+  {
+    const int t = xcd_remap(blockIdx.x, T);
+    la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+    lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+  }
+  auto prefetch = [&](unsigned short* stage) {                   // issue the slot at the prefetch position, advance it
+    la.issue(pkt * BK3, stage);
+    lbld.issue(pkt * BK3, stage + AOPER);
+    if (++pkt == nkt) {
+      pkt = 0; ++pj;
+      if (pj < ntl) {
+        const int t = xcd_remap(blockIdx.x + pj * G, T);
+        la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+        lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int s0 = 0; s0 < NST; ++s0)
+    if (s0 < total) prefetch(smem + s0 * STAGE);
+
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
+  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+
+  u32x4 fa[2][2][3], fb[2][2][3];
+#define DIC_PIPE_READ_A(KS_, SB_, I_)                                                                                \
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+      bf3_lds_read(fa[KS_][I_][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)((I_) * 32 * 64) + pos[KS_]);
+#define DIC_PIPE_READ_B(KS_, SB_, J_)                                                                                \
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+      bf3_lds_read(fb[KS_][J_][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)((J_) * 32 * 64) + pos[KS_]);
+#define DIC_PIPE_PIN(KS_)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
+#define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
+                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
+
+  if (total > NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (NST - 1)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
+
+  int g = 0, st = 0;                               // slot, its ring stage
+  int since_seam = 2;                              // slots since a FULL tile's 64 + 4 stores were issued (>= 2: none in range)
+  for (int j = 0; j < ntl; ++j) {
+    for (int kt = 0; kt < nkt; ++kt, ++g) {
+      const int stn = st == NST - 1 ? 0 : st + 1;
+      const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
+      unsigned short* cur = smem + st * STAGE;
+      DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
+      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      DIC_PIPE_PIN(0)
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      // Slot g+1 (issued two slots ago) must have landed.  Younger than it, in issue order: slot g+2's 12 DMA instructions
+      // and, if a seam lies less than two slots back, that tile's 64 stores (+ statistics): >= 63 operations, so "at most
+      // 63 outstanding" already implies slot g+1 - without waiting for the stores' acknowledgements.
+      if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (since_seam < 2) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      DIC_PIPE_PIN(1)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_PIPE_MFMA(1, 2, 0)
+      if (g + 1 < total) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
+      DIC_PIPE_MFMA(1, 0, 2)
+      if (g + NST < total) prefetch(cur);
+      DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      st = stn;
+      ++since_seam;
+    }
+    // ---- seam: store the tile (the next tile's first fragments and two slots of DMA are already under way)
+    const int t = xcd_remap(blockIdx.x + j * G, T);
+    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
+              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
+          cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
+          acc[i][jj][r] = 0.f;
+        }
+      }
+    if (p.ep.stats) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
+        const int n = n0 + jj * 32;
+        if (lane < 32 && n < p.N) {
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 0) * p.N + n] = a;
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 1) * p.N + n] = b;
+        }
+      }
+    }
+    since_seam = full ? 0 : 2;
+  }
+#undef DIC_PIPE_READ_A
+#undef DIC_PIPE_READ_B
+#undef DIC_PIPE_PIN
+#undef DIC_PIPE_MFMA
+}
+
 }  // namespace dic
 
 namespace dic {
@@ -350,6 +619,8 @@ static int g_bf3_force = 0;     // benchmarking: 11 / 21 / 22 force the 64x64 / 
 void gemm_bf3_force_tile(int code);
 
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
+static int g_bf3_persist_grid = 256;   // persistent kernel: workgroups (one per CU)
+static int g_bf3_persist_policy = 2;   // benchmarking (codes 70..72): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids
 static int g_bf3_tail_mode = 0; // benchmarking (codes 60..63): 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 template <int AK, int TM, int TN>
@@ -365,6 +636,7 @@ void gemm_bf3_force_tile(int code) {
   if (code == 43) { g_bf3_stages = 3; return; }
   if (code >= 50 && code <= 52) { g_bf3_ablate = code - 50; return; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return; }
+  if (code >= 70 && code <= 72) { g_bf3_persist_policy = code - 70; return; }
   g_bf3_force = code;
 }
 
@@ -390,7 +662,19 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   if (t11 >= 1024 && p.K >= 1024) { tmv = 2; tnv = 1; }
   if (g_bf3_force == 11) { tmv = 1; tnv = 1; }
   if (g_bf3_force == 21) { tmv = 2; tnv = 1; }
-  if (g_bf3_force == 22) { tmv = 2; tnv = 2; }
+  if (g_bf3_force == 22 || g_bf3_force == 23) { tmv = 2; tnv = 2; }
+  // Persistent 128x128 kernel: plain-store epilogue without bias, at least two K tiles.  Policy (scripts/bench_bf3_pipe.py):
+  // it wins where a tile is only a few K tiles long and the grid is many rounds deep - the 1x1 expansions 64 -> 256
+  // (-12 % per launch at batch 64, -20 % at batch 256), and at batch-256 scale also 128 -> 512 and 256 -> 1024.
+  const bool persist_ok = splitk <= 1 && !p.ep.bias && !p.ep.accumulate && !p.ep.row_map && !p.ep.C2 && p.ep.act == ACT_NONE &&
+                          p.K > BK3 && p.N % 128 == 0;
+  const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+  bool persist = persist_ok && g_bf3_force == 0 && g_bf3_persist_policy != 0 &&
+                 ((p.K <= 64 && t22 >= 1024) || (g_bf3_persist_policy >= 2 && p.K <= 256 && t22 >= 3072));
+  if (g_bf3_force == 24) persist = persist_ok;
+  if (g_bf3_force == 24 || persist) { tmv = 2; tnv = 2; }
+  const bool pipe = tmv == 2 && tnv == 2 && g_bf3_force != 22;       // 128x128 = the deep-pipelined kernel (22: the plain loop)
+  persist = persist && pipe;
   p.mtiles = ceil_div(p.M, 64 * tmv); p.ntiles = ceil_div(p.N, 64 * tnv);
   g_last_mtiles = p.mtiles;
   p.splitk = 1; p.ws = nullptr;
@@ -420,8 +704,19 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   const bool im = p.A.kind == OPK_IM2COL;
-  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (tmv - 1) * 2 + (tnv - 1));
-  if (tmv == 2 && tnv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 2>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 2>(p, total, st); }
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
+  if (persist) {
+    g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
+    const int grid = std::min(T, g_bf3_persist_grid);
+    if (im) hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_IM2COL>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_ROWK>), dim3(grid), dim3(256), 0, st, p);
+  } else if (pipe && g_bf3_stages == 3) {
+    if (im) hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_IM2COL, 3>), dim3(total), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 3>), dim3(total), dim3(256), 0, st, p);
+  } else if (pipe) {
+    if (im) hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_IM2COL, 2>), dim3(total), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 2>), dim3(total), dim3(256), 0, st, p);
+  } else if (tmv == 2 && tnv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 2>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 2>(p, total, st); }
   else if (tmv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 1>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 1>(p, total, st); }
   else if (!im && g_bf3_ablate == 1) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 1>), dim3(total), dim3(256), 0, st, p);
   else if (!im && g_bf3_ablate == 2) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 2>), dim3(total), dim3(256), 0, st, p);
