@@ -43,7 +43,7 @@ int dic_debug_force_staged_gemm(int on) {
   if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement   // decoder forward: per-step launches / persistent loop
   if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
-  if (on == 11 || on == 21 || on == 22 || on == 23 || on == 24 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 52) || (on >= 60 && on <= 63) || (on >= 70 && on <= 72)) gemm_bf3_force_tile(on == 20 ? 0 : on);
+  if (on == 11 || on == 21 || on == 22 || on == 23 || on == 24 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 53) || (on >= 60 && on <= 63) || (on >= 70 && on <= 77)) gemm_bf3_force_tile(on == 20 ? 0 : on);
   else if (on >= 0 && on <= 13) gemm_force_v1(on);
   else DIC_REQUIRE(false, "debug switch: unknown code");
   return 0;
@@ -61,6 +61,13 @@ int dic_debug_conv1_fwd(const float* x, int B, int H, int W, const float* w, con
   ConvDesc d{B, H, W, 1, 128, 7, 7, 3, 0, 0};
   int rows = 0;
   return conv1_depth_fwd(x, d, w, bias, y, partial, &rows, (hipStream_t)stream);
+}
+/* development aid (not in dic.h): one split-bf16 convolution with train-mode BatchNorm partial sums, from paired planes
+ * (dic_split_bf16x3_paired of the NHWC input viewed as [B*H*W][C] and of the OHWI weight viewed as [CO][KH*KW*C]) */
+int dic_debug_conv_bf3(const uint16_t* const x_planes[3], int B, int H, int W, int C, const uint16_t* const w_planes[3], int CO,
+                       int k, int stride, int pad, float* y, float* bn_partial, int* mtiles_out, float* tail_ws, void* stream) {
+  ConvDesc d{B, H, W, C, CO, k, k, stride, pad, 0};
+  return conv_fwd_bf3(x_planes, d, w_planes, y, bn_partial, mtiles_out, tail_ws, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {

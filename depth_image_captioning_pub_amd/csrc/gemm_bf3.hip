@@ -93,7 +93,7 @@ struct Bf3Loader {
   __device__ __forceinline__ void init(const Bf3Operand& op, int r0, int R, int K_) {
     p[0] = op.p[0]; p[1] = op.p[1]; p[2] = op.p[2];
     K = K_; C = op.g.C; KW = op.g.KW; W = op.g.W; paired = op.paired;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;      // (& 3: producer waves 4..7 of the warp-specialised kernels)
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int row = (n * 4 + w) * 16 + (lane >> 2);
@@ -128,7 +128,7 @@ struct Bf3Loader {
 
   // img: this operand's [3][BR][32] bf16 image of one stage
   __device__ __forceinline__ void issue(int k0, unsigned short* img) const {
-    const int w = threadIdx.x >> 6;
+    const int w = (threadIdx.x >> 6) & 3;
     int tap = 0, dpix = 0;
     long long uni = paired ? (long long)(k0 >> 5) * 64 : (long long)k0;
     if constexpr (KIND == OPK_IM2COL) {
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 //     neither wait stalls in steady state; after the barrier the stage just read is re-filled with tile it+2;
 //   * DMA issue and fragment reads are placed textually inside the MFMA runs (MFMA issue leaves 7 of 8 slots free).
 // Same per-element summation order as gemm_bf3_kernel (K ascending, small products first): bit-identical results.
-template <int AK, int NST>
+template <int AK, int NST, int ABL = 0>      // ABL (measurement only): 1 = no DMA inside the loop, 2 = also no barrier, 3 = also no fragment reads
 __global__ void __launch_bounds__(256) gemm_bf3_pipe_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(256) gemm_bf3_pipe_kernel(const Bf3Params p) {
     const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
     unsigned short* cur = smem + st * STAGE;
     // ---- k-step 0: its fragments were requested one k-step ago; request k-step 1 of this tile
-    DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
-    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    if constexpr (ABL < 3) { DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1) }
+    if constexpr (ABL < 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
     DIC_PIPE_PIN(0)
     __builtin_amdgcn_sched_barrier(0);
     // small terms first: al*bh, ah*bl, am*bm, am*bh, ah*bm, ah*bh   (plane 0 = hi, 1 = mid, 2 = lo)
@@ -425,15 +425,15 @@ __global__ void __launch_bounds__(256) gemm_bf3_pipe_kernel(const Bf3Params p) {
     if (NST == 2 || it + NST - 1 >= nkt) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(12 * (NST - 2)) : "memory");
     DIC_PIPE_PIN(1)
-    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL < 2) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- k-step 1, with the refill of this stage (tile it+2) and the next tile's k-step-0 reads in its shadow
     DIC_PIPE_MFMA(1, 2, 0)
-    if (it + 1 < nkt) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
+    if (ABL < 3 && it + 1 < nkt) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
     DIC_PIPE_MFMA(1, 0, 2)
-    if (it + NST < nkt) la.issue((it + NST) * BK3, cur);
+    if (ABL == 0 && it + NST < nkt) la.issue((it + NST) * BK3, cur);
     DIC_PIPE_MFMA(1, 1, 1)
-    if (it + NST < nkt) lbld.issue((it + NST) * BK3, cur + AOPER);
+    if (ABL == 0 && it + NST < nkt) lbld.issue((it + NST) * BK3, cur + AOPER);
     DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -610,6 +610,409 @@ __global__ void __launch_bounds__(256) gemm_bf3_persist_kernel(const Bf3Params p
 #undef DIC_PIPE_MFMA
 }
 
+
+// Warp-specialised form of gemm_bf3_persist_kernel: waves 0..3 only compute (fragment reads, MFMAs, stores), waves 4..7 only
+// move operands (LDS-DMA issue and the counted vmcnt that says a slot has landed); both meet at the one barrier per K tile.
+// Why: with DMA issue inside the computing waves a K tile costs 3500-4000 cycles against 2500-2600 without any DMA
+// (scripts/bench_bf3_pipe_ablate.py) - a global_load_lds that cannot issue (address arithmetic, M0 set-up, a full
+// vector-memory queue) blocks the MFMAs queued behind it in the same wave.  A producer wave that blocks costs nothing.
+// Two waves per SIMD, so the kernel has to fit 256 registers; the stores of a seam and the DMA no longer share a vmcnt.
+template <int AK>
+__global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
+  constexpr int BM = 128, BN = 128, NST = 3;
+  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
+  __shared__ __align__(1024) unsigned short smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = (p.K + BK3 - 1) / BK3;
+  const int T = p.mtiles * p.ntiles, G = gridDim.x;
+  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
+  const int total = ntl * nkt;
+
+  if (wave >= 4) {
+    // ---------------- producer waves: slot g of the stream goes to ring stage g % NST
+    Bf3Loader<AK, BM> la;
+    Bf3Loader<OPK_ROWK, BN> lbld;
+    int pj = 0, pkt = 0;
+    {
+      const int t = xcd_remap(blockIdx.x, T);
+      la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+      lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+    }
+    auto prefetch = [&](unsigned short* stage) {
+      la.issue(pkt * BK3, stage);
+      lbld.issue(pkt * BK3, stage + AOPER);
+      if (++pkt == nkt) {
+        pkt = 0; ++pj;
+        if (pj < ntl) {
+          const int t = xcd_remap(blockIdx.x + pj * G, T);
+          la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+          lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+        }
+      }
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0)
+      if (s0 < total) prefetch(smem + s0 * STAGE);
+    if (total >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (NST - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
+    int st = 0;
+    for (int g = 0; g < total; ++g) {
+      // before the consumers read slot g+1 (after this barrier) it must have landed; slot g+2 may stay in flight
+      if (g + 2 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
+      if (g + NST < total) prefetch(smem + st * STAGE);
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+    return;
+  }
+
+  // ---------------- consumer waves
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
+  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+  u32x4 fa[2][2][3], fb[2][2][3];
+#define DIC_PIPE_READ_A(KS_, SB_, I_)                                                                                \
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+      bf3_lds_read(fa[KS_][I_][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)((I_) * 32 * 64) + pos[KS_]);
+#define DIC_PIPE_READ_B(KS_, SB_, J_)                                                                                \
+  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+      bf3_lds_read(fb[KS_][J_][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)((J_) * 32 * 64) + pos[KS_]);
+#define DIC_PIPE_PIN(KS_)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
+#define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
+                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
+  __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
+  DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
+  int g = 0, st = 0;
+  for (int j = 0; j < ntl; ++j) {
+    for (int kt = 0; kt < nkt; ++kt, ++g) {
+      const int stn = st == NST - 1 ? 0 : st + 1;
+      const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
+      DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
+      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      DIC_PIPE_PIN(0)
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this stage is in registers
+      DIC_PIPE_PIN(1)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_PIPE_MFMA(1, 2, 0)
+      if (g + 1 < total) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
+      DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      st = stn;
+    }
+    // ---- seam: store the tile
+    const int t = xcd_remap(blockIdx.x + j * G, T);
+    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
+              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
+          cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
+          acc[i][jj][r] = 0.f;
+        }
+      }
+    if (p.ep.stats) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
+        const int n = n0 + jj * 32;
+        if (lane < 32 && n < p.N) {
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 0) * p.N + n] = a;
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 1) * p.N + n] = b;
+        }
+      }
+    }
+  }
+#undef DIC_PIPE_READ_A
+#undef DIC_PIPE_READ_B
+#undef DIC_PIPE_PIN
+#undef DIC_PIPE_MFMA
+}
+
+// 3x3 / stride-1 / pad-1 convolution on 14x14 maps (ResNet layer 3: 36 of the 50 3x3 convolutions) with the input tile's HALO
+// staged in LDS instead of an im2col gather.  Why: the contraction kernels of this file are bound by operand intake per CU
+// (see gemm_bf3_persist_kernel), and the gather is the worst customer - every tap re-fetches the same pixels as 64-B halves
+// of 128-B lines, 24 KB per K tile.  Here the K loop is ordered (32-channel chunk, tap): the 13 padded image rows x 16
+// padded pixels that the 128 output pixels of a tile touch are copied ONCE per chunk (39 KB incl. zero padding, whole
+// 128-B lines), and the nine taps read their A fragments from that image at shifted pixel offsets; only the weights
+// (24 KB per tap) still stream: 24 + 39/9 = 28 KB per K tile instead of 48.
+//   * padded-row index space: image b owns rows b*(H+1)+1 .. b*(H+1)+H, the rows b*(H+1) are zero and shared between
+//     neighbouring images; padded column 0 and W+1.. are zero; a tile's rows are pr_lo .. pr_lo+12 (<= 13 for any tile);
+//   * LDS: 2 halo buffers (chunk parity) x 3 planes x 13 rows x 16 pixels x 64 B + a 3-stage ring of weight tiles + 1 KB that
+//     absorbs one dummy DMA per chunk so that every wave issues exactly 10 halo instructions (counted vmcnt);
+//   * pipeline = gemm_bf3_persist_kernel: persistent over output tiles, fragments double-buffered by k-step, one barrier
+//     per K tile, weights three tiles ahead, the next chunk's halo issued at tap 0 of the current chunk (8 K tiles early);
+//   * summation order per output: chunk-major, tap-minor (the other kernels: tap-major) - same products, fp32-level
+//     differences in the last bit, not bit-identical to them.
+template <int ABL>      // ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
+__global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p) {
+  constexpr int BM = 128, BN = 128, NSTB = 3, HROW = 16, RMAX = 13;
+  constexpr int HPLANE = RMAX * HROW * BK3, HBUF = 3 * HPLANE;        // elements: 13 KB per plane, 39 KB per buffer
+  constexpr int BPLANE = BN * BK3, BSTAGE = 3 * BPLANE;               // 24 KB per weight tile
+  constexpr int NHALO = 10;                                            // halo DMA instructions per producer wave and chunk
+  __shared__ __align__(1024) unsigned short smem[2 * HBUF + NSTB * BSTAGE + 512];
+  unsigned short* const bring = smem + 2 * HBUF;
+  unsigned short* const dummy = smem + 2 * HBUF + NSTB * BSTAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.A.g.H, W = p.A.g.W, C = p.A.g.C, ohw = H * W, nimg = p.M / ohw;
+  const int NC = C / BK3, per_tile = NC * 9;
+  const int T = p.mtiles * p.ntiles, G = gridDim.x;
+  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
+  const int total = ntl * per_tile, nchunks = ntl * NC;
+
+  auto tile_of = [&](int j, int& tm, int& tn) { const int t = xcd_remap(blockIdx.x + j * G, T); tm = t / p.ntiles; tn = t - tm * p.ntiles; };
+  auto row_lo = [&](int tm) {                     // first padded row of the tile's halo
+    const int m0 = tm * BM, b0 = m0 / ohw, oy0 = (m0 - b0 * ohw) / W;
+    return b0 * (H + 1) + oy0;
+  };
+
+  if (wave >= 4) {
+    // ================= producer waves (4..7 -> w = 0..3): all LDS-DMA of the workgroup
+    const int w = wave - 4;
+    // halo chunk n = (tile n / NC, channels 32*(n % NC) ..) into buffer n & 1.  The source offsets of this wave's ten
+    // (row, plane) instructions depend on the tile only: derived once per tile (integer divisions), reused by its NC chunks
+    int hoff[NHALO];                                        // element offset of this lane's 16 bytes, chunk 0
+    unsigned hok = 0u;                                      // bit t: instruction t reads real data (else the zero line)
+    auto setup_halo = [&](int j) {
+      int tm, tn;
+      tile_of(j, tm, tn);
+      const int pr_lo = row_lo(tm), px = lane >> 2, ix = px - 1;
+      int b = pr_lo / (H + 1), rr = pr_lo - b * (H + 1);    // padded row pr_lo + r = image b, row rr (0 = the shared zero row)
+      int r_prev = 0;
+      hok = 0u;
+#pragma unroll
+      for (int t = 0; t < NHALO; ++t) {
+        const int idx = w + 4 * t;                          // (row, plane) = (idx / 3, idx % 3); idx 39 = the dummy
+        const int r = (idx * 43) >> 7;
+        for (int a = r_prev; a < r; ++a) { if (++rr == H + 1) { rr = 0; ++b; } }      // at most two steps
+        r_prev = r;
+        const int q = r * HROW + px, c16 = (lane & 3) ^ ((q >> 2) & 3);
+        const int pix = (b * H + rr - 1) * W + ix;
+        hoff[t] = (pix >> 1) * (C * 2) + ((pix & 1) << 5) + c16 * 8;
+        if (r < RMAX && rr != 0 && b < nimg && (unsigned)ix < (unsigned)W) hok |= 1u << t;
+      }
+    };
+    auto issue_halo = [&](int n) {
+      const int cc = n % NC;
+      if (cc == 0) setup_halo(n / NC);
+      unsigned short* buf = smem + (n & 1) * HBUF;
+#pragma unroll
+      for (int t = 0; t < NHALO; ++t) {
+        const int idx = w + 4 * t, r = (idx * 43) >> 7, pl = idx - 3 * r;
+        const unsigned short* src = ((hok >> t) & 1u) ? p.A.p[pl < 3 ? pl : 0] + (hoff[t] + cc * 64) : g_zero_line16;
+        unsigned short* dst = r < RMAX ? buf + pl * HPLANE + r * (HROW * BK3) : dummy;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    // weight slot s = (tile, chunk, tap) in that order, K offset tap*C + 32*chunk
+    Bf3Loader<OPK_ROWK, BN> lbld;
+    int pj = 0, pcc = 0, ptap = 0, pst = 0;
+    { int tm, tn; tile_of(0, tm, tn); lbld.init(p.B, tn * BN, p.N, p.K); }
+    auto issue_b = [&]() {
+      lbld.issue(ptap * C + pcc * BK3, bring + pst * BSTAGE);
+      pst = pst == NSTB - 1 ? 0 : pst + 1;
+      if (++ptap == 9) {
+        ptap = 0;
+        if (++pcc == NC) {
+          pcc = 0; ++pj;
+          if (pj < ntl) { int tm, tn; tile_of(pj, tm, tn); lbld.init(p.B, tn * BN, p.N, p.K); }
+        }
+      }
+    };
+    issue_halo(0);
+#pragma unroll
+    for (int s0 = 0; s0 < NSTB; ++s0)
+      if (s0 < total) issue_b();
+    if (total >= NSTB) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // halo chunk 0 and weight tile 0 (6 each younger tile)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int g = 0, n = 0;
+    bool halo_prev = false;                        // the previous slot issued a halo chunk (10 instructions before its weights)
+    for (int j = 0; j < ntl; ++j)
+      for (int cc = 0; cc < NC; ++cc, ++n)
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++g) {
+          // weight tile g+1 (and, before tap 0 of a chunk, that chunk's halo - older still) must have landed; younger, in issue
+          // order: the previous slot's halo chunk (10, if it issued one) and weight tile g+2 (6)
+          if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (halo_prev) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          halo_prev = false;
+          if (tap == 0 && n + 1 < nchunks) { if (!(ABL & 2)) issue_halo(n + 1); halo_prev = !(ABL & 2); }
+          if (!(ABL & 1) && g + NSTB < total) issue_b();
+        }
+    return;
+  }
+
+  // ================= consumer waves
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i31 = lane & 31, h = lane >> 5;
+  auto pixel_base = [&](int tm, int i) {                // LDS pixel index of the top-left tap of this lane's output row
+    int m = tm * BM + wm * 64 + i * 32 + i31;
+    m = min(m, p.M - 1);
+    const int b = m / ohw, rem = m - b * ohw, oy = rem / W, ox = rem - oy * W;
+    return (b * (H + 1) + oy - row_lo(tm)) * HROW + ox;
+  };
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+  const unsigned offB = (unsigned)((wn * 64 + i31) * 64), bkey = (unsigned)((i31 >> 2) & 3);
+  const unsigned posB[2] = {(unsigned)(((0 + h) ^ bkey) * 16), (unsigned)(((2 + h) ^ bkey) * 16)};
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u32x4 fa[2][2][3], fb[2][2][3];
+  // A fragments of k-step KS_: pixel q = QB_[i] + 16*kh + kw of halo buffer HB_, 16-B slot (2*KS_ + h) ^ key(q)
+#define DIC_HALO_READ_A(KS_, HB_, QB_, TAPOFF_)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                    \
+    const unsigned q = (unsigned)((QB_)[i] + (TAPOFF_));                                                             \
+    const unsigned a = sbase0 + (unsigned)((HB_) * HBUF * 2) + q * 64u + ((((unsigned)(2 * (KS_) + h)) ^ ((q >> 2) & 3u)) << 4); \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) bf3_lds_read(fa[KS_][i][pl], a + (unsigned)(pl * HPLANE * 2));  \
+  }
+#define DIC_HALO_READ_B(KS_, ST_)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
+      bf3_lds_read(fb[KS_][j][pl], sbase0 + (unsigned)((2 * HBUF + (ST_) * BSTAGE + pl * BPLANE) * 2) + offB + (unsigned)(j * 32 * 64) + posB[KS_]);
+#define DIC_PIPE_PIN(KS_)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
+#define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
+                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
+
+  int qb[2], qbn[2];
+  { int tm, tn; tile_of(0, tm, tn); qb[0] = pixel_base(tm, 0); qb[1] = pixel_base(tm, 1); }
+  qbn[0] = qb[0]; qbn[1] = qb[1];
+  __builtin_amdgcn_s_barrier();                    // halo chunk 0 and weight tile 0 are in LDS
+  DIC_HALO_READ_A(0, 0, qb, 0) DIC_HALO_READ_B(0, 0)
+
+  int g = 0, st = 0, n = 0;                        // slot, its weight stage, its (global) chunk
+  for (int j = 0; j < ntl; ++j) {
+    for (int cc = 0; cc < NC; ++cc, ++n) {
+      const int hb = n & 1;
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap, ++g) {
+        const int stn = st == NSTB - 1 ? 0 : st + 1;
+        const int kh = tap >= 6 ? 2 : tap >= 3 ? 1 : 0, kw = tap - 3 * kh, tapoff = kh * HROW + kw;
+        DIC_HALO_READ_A(1, hb, qb, tapoff) DIC_HALO_READ_B(1, st)
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        DIC_PIPE_PIN(0)
+        __builtin_amdgcn_sched_barrier(0);
+        DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DIC_PIPE_PIN(1)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        DIC_PIPE_MFMA(1, 2, 0)
+        if (g + 1 < total) {                       // k-step 0 of the next slot: next tap / next chunk (other buffer) / next tile
+          if (tap < 8) {
+            const int t1 = tap + 1, kh1 = t1 >= 6 ? 2 : t1 >= 3 ? 1 : 0, off1 = kh1 * HROW + (t1 - 3 * kh1);
+            DIC_HALO_READ_A(0, hb, qb, off1)
+          } else if (cc + 1 < NC) {
+            DIC_HALO_READ_A(0, hb ^ 1, qb, 0)
+          } else {
+            DIC_HALO_READ_A(0, hb ^ 1, qbn, 0)
+          }
+          DIC_HALO_READ_B(0, stn)
+        }
+        DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0)
+        if (tap == 1 && cc == NC - 1 && j + 1 < ntl) {        // next tile's pixel bases, well before its first fragment reads
+          int tm, tn; tile_of(j + 1, tm, tn);
+          qbn[0] = pixel_base(tm, 0); qbn[1] = pixel_base(tm, 1);
+        }
+        DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        st = stn;
+      }
+    }
+    // ---- seam
+    int tm, tn;
+    tile_of(j, tm, tn);
+    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+            cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N) {   // rows past M repeat the last pixel: masked
+              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+              cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+      }
+    if (p.ep.stats) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
+        const int nn = n0 + jj * 32;
+        if (lane < 32 && nn < p.N) {
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 0) * p.N + nn] = a;
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 1) * p.N + nn] = b;
+        }
+      }
+    }
+    qb[0] = qbn[0]; qb[1] = qbn[1];
+  }
+#undef DIC_HALO_READ_A
+#undef DIC_HALO_READ_B
+#undef DIC_PIPE_PIN
+#undef DIC_PIPE_MFMA
+}
+
 }  // namespace dic
 
 namespace dic {
@@ -620,7 +1023,9 @@ void gemm_bf3_force_tile(int code);
 
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
 static int g_bf3_persist_grid = 256;   // persistent kernel: workgroups (one per CU)
-static int g_bf3_persist_policy = 2;   // benchmarking (codes 70..72): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids
+static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
+static int g_bf3_halo = 1;             // codes 74 / 75: 3x3 convolutions of 14x14 maps on the LDS-halo kernel on / off
+static int g_bf3_persist_policy = 3;   // benchmarking (codes 70..73): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = by CU fill
 static int g_bf3_tail_mode = 0; // benchmarking (codes 60..63): 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 template <int AK, int TM, int TN>
@@ -634,9 +1039,11 @@ static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
 void gemm_bf3_force_tile(int code) {
   if (code == 42) { g_bf3_stages = 2; return; }
   if (code == 43) { g_bf3_stages = 3; return; }
-  if (code >= 50 && code <= 52) { g_bf3_ablate = code - 50; return; }
+  if (code >= 50 && code <= 53) { g_bf3_ablate = code - 50; return; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return; }
-  if (code >= 70 && code <= 72) { g_bf3_persist_policy = code - 70; return; }
+  if (code >= 70 && code <= 73) { g_bf3_persist_policy = code - 70; return; }
+  if (code == 74 || code == 75) { g_bf3_halo = code == 74; return; }
+  if (code == 76 || code == 77) { g_bf3_ws = code == 76; return; }
   g_bf3_force = code;
 }
 
@@ -669,9 +1076,23 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   const bool persist_ok = splitk <= 1 && !p.ep.bias && !p.ep.accumulate && !p.ep.row_map && !p.ep.C2 && p.ep.act == ACT_NONE &&
                           p.K > BK3 && p.N % 128 == 0;
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-  bool persist = persist_ok && g_bf3_force == 0 && g_bf3_persist_policy != 0 &&
-                 ((p.K <= 64 && t22 >= 1024) || (g_bf3_persist_policy >= 2 && p.K <= 256 && t22 >= 3072));
+  const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
+  const double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
+  bool persist = false;
+  if (persist_ok && g_bf3_force == 0) {
+    if (g_bf3_persist_policy == 1) persist = p.K <= 64 && t22 >= 1024;
+    else if (g_bf3_persist_policy == 2) persist = (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
+    else if (g_bf3_persist_policy >= 3)     // warp-specialised form (scripts/bench_bf3_pipe.py at batch 64 and 256): wins wherever the
+      persist = (p.A.kind == OPK_ROWK && t22 >= 192 && (fill22 >= 0.85 || (fill22 >= 0.75 && p.K >= 512))) ||      // tiles fill the CUs
+                (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
+  }
   if (g_bf3_force == 24) persist = persist_ok;
+  // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
+  const ConvGeom& cg = p.A.g;
+  const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && t22 >= 128 && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
+                    cg.stride == 1 && cg.pad == 1 && cg.H == 14 && cg.W == 14 && cg.nchw == 0 && cg.C % BK3 == 0 &&
+                    p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
+  if (halo) persist = true;
   if (g_bf3_force == 24 || persist) { tmv = 2; tnv = 2; }
   const bool pipe = tmv == 2 && tnv == 2 && g_bf3_force != 22;       // 128x128 = the deep-pipelined kernel (22: the plain loop)
   persist = persist && pipe;
@@ -704,12 +1125,24 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   const bool im = p.A.kind == OPK_IM2COL;
-  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
   if (persist) {
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
-    const int grid = std::min(T, g_bf3_persist_grid);
-    if (im) hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_IM2COL>), dim3(grid), dim3(256), 0, st, p);
+    // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
+    const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
+    if (!halo && g_bf3_ws) {
+      if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
+    } else if (halo && g_bf3_ablate == 1) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<1>, dim3(grid), dim3(512), 0, st, p);
+    else if (halo && g_bf3_ablate == 2) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<2>, dim3(grid), dim3(512), 0, st, p);
+    else if (halo && g_bf3_ablate == 3) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<3>, dim3(grid), dim3(512), 0, st, p);
+    else if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<0>, dim3(grid), dim3(512), 0, st, p);
+    else if (im) hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_IM2COL>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_ROWK>), dim3(grid), dim3(256), 0, st, p);
+  } else if (pipe && g_bf3_ablate > 0 && !im) {
+    if (g_bf3_ablate == 1) hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 2, 1>), dim3(total), dim3(256), 0, st, p);
+    else if (g_bf3_ablate == 2) hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 2, 2>), dim3(total), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 2, 3>), dim3(total), dim3(256), 0, st, p);
   } else if (pipe && g_bf3_stages == 3) {
     if (im) hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_IM2COL, 3>), dim3(total), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 3>), dim3(total), dim3(256), 0, st, p);

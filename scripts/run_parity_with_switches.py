@@ -1,0 +1,9 @@
+import os, sys as _s; _s.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, torch
+torch.cuda.init(); torch.zeros(1, device="cuda:0")
+from depth_image_captioning_pub_amd import _lib
+l = _lib.load()
+for c in sys.argv[1:]:
+    l.dic_debug_force_staged_gemm(int(c))
+import pytest
+sys.exit(pytest.main(["tests/test_fullsize_parity_gpu.py", "-q", "-m", "gpu", "-s", "-k", "32"]))
