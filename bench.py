@@ -71,6 +71,13 @@ def profile_step(trainer, args_step):
         k = keys[i]
         if k >= 2000:                                   # split-bf16 convolution kernel (gemm_bf3.hip)
             a, tcode = (k - 2000) // 10, (k - 2000) % 10
+            if tcode >= 4:                                  # 128x128: deep-pipelined / persistent (warp-specialised) / LDS-halo 3x3
+                name, rname = {4: (f"gemm_bf3_pipe_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_pipe_kernel<{a}, "),
+                               5: (f"gemm_bf3_persist_ws_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws_kernel<{a}>"),
+                               6: ("conv3x3_bf3_halo_kernel", "conv3x3_bf3_halo_kernel<0>")}[tcode]
+                rows.append({"kernel": name, "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i],
+                             "peak": PEAK_BF16X3_TFLOPS})
+                continue
             tm, tn = 1 + tcode // 2, 1 + tcode % 2          # workgroup tile 64*tm x 64*tn
             tile = "" if (tm, tn) == (1, 1) else f",{64 * tm}x{64 * tn}"
             rows.append({"kernel": f"gemm_bf3_kernel<{KIND_NAMES[a]}{tile}>",

@@ -1024,7 +1024,7 @@ void gemm_bf3_force_tile(int code);
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
 static int g_bf3_persist_grid = 256;   // persistent kernel: workgroups (one per CU)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
-static int g_bf3_halo = 1;             // codes 74 / 75: 3x3 convolutions of 14x14 maps on the LDS-halo kernel on / off
+static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the LDS-halo kernel: 0 = off (code 75), 1 = from 128 tiles (78, default), 2 = always (74)
 static int g_bf3_persist_policy = 3;   // benchmarking (codes 70..73): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = by CU fill
 static int g_bf3_tail_mode = 0; // benchmarking (codes 60..63): 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
@@ -1042,7 +1042,7 @@ void gemm_bf3_force_tile(int code) {
   if (code >= 50 && code <= 53) { g_bf3_ablate = code - 50; return; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return; }
   if (code >= 70 && code <= 73) { g_bf3_persist_policy = code - 70; return; }
-  if (code == 74 || code == 75) { g_bf3_halo = code == 74; return; }
+  if (code == 74 || code == 75 || code == 78) { g_bf3_halo = code == 74 ? 2 : code == 78 ? 1 : 0; return; }
   if (code == 76 || code == 77) { g_bf3_ws = code == 76; return; }
   g_bf3_force = code;
 }
@@ -1089,7 +1089,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   if (g_bf3_force == 24) persist = persist_ok;
   // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
   const ConvGeom& cg = p.A.g;
-  const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && t22 >= 128 && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
+  const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
                     cg.stride == 1 && cg.pad == 1 && cg.H == 14 && cg.W == 14 && cg.nchw == 0 && cg.C % BK3 == 0 &&
                     p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
   if (halo) persist = true;

@@ -314,9 +314,13 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind; 2000 + 10*A_kind = bf16x3 kernel), total milliseconds, algorithmic FLOPs and launches. */
 /* Benchmarking / ablation switches (process-global, used by scripts/ only; results stay correct under every code):
  *   0 / 1        LDS-DMA kernels (default) / every exact-fp32 contraction on the register-staged kernel (v1)
- *   11 21 22 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / 128x128 / policy default
+ *   11 21 22 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / 128x128 (plain loop) / policy default
+ *   23 24        ... forced to the deep-pipelined 128x128 kernel / its persistent form (wherever its epilogue applies)
  *   42 43        ring depth 2 / 3 of the 128-wide bf16x3 variants
- *   50 51 52     bf16x3 64x64 ablation: full / no DMA in the loop / MFMA only
+ *   50 51 52 53  ablations of the kernel selected by 11 / 23 / the halo kernel: full / no DMA in the loop / ... (scripts/bench_bf3_*ablate*.py)
+ *   70..73       persistent kernel by policy: never / K <= 64 / + K <= 256 on >= 3072-tile grids / by CU fill (default)
+ *   76 77        persistent kernel warp-specialised, 4 compute + 4 DMA waves (default) / DMA issued by the computing waves
+ *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
  *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
  *   120 121      tail fix-up and BatchNorm finalize in separate launches / fused (default)
  *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
@@ -325,7 +329,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   130..134     depth-encoder layer 1: generic MFMA gather path (default) / packed-FMA kernels with 256, 512, 768, 1024 workgroups
  *                (off by default: not bit-reproducible next to a concurrent bf16x3 forward, see csrc/conv1_depth.hip)
  * Unknown codes are rejected (DIC_ERR_ARG).
- * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + 2*(tile_m/64 - 1) + (tile_n/64 - 1). */
+ * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,
+ * 4 = deep-pipelined 128x128, 5 = persistent 128x128, 6 = LDS-halo 3x3. */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);

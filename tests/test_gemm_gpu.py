@@ -229,7 +229,8 @@ def test_gemm_bf16x3_tile_variants_are_bit_identical(lib, M, N, K):
     ascending: 64x64 (code 11), 128x64 (21), the deep-pipelined 128x128 kernel (23: fragment double-buffering across K
     tiles, one barrier per K tile) and its persistent form (24: one workgroup per CU streams the K tiles of all its output
     tiles through a 3-stage ring, stores at the seams under a counted vmcnt) must agree bit for bit - ragged edges, a single
-    tile, many seams per workgroup (33000 x 256 x 64 = 516 tiles of two K tiles on 256 workgroups) and long K included."""
+    tile, many seams per workgroup (33000 x 256 x 64 = 516 tiles of two K tiles on 256 workgroups) and long K included.
+    The persistent kernel runs in both forms: DMA issued by the computing waves (code 77) and by four producer waves (76)."""
     g = torch.Generator().manual_seed(3 * M + K)
     A = torch.randn(M, K, generator=g).to(DEV)
     B = (torch.randn(N, K, generator=g) * torch.logspace(-2, 2, N).unsqueeze(1)).to(DEV)
@@ -244,8 +245,9 @@ def test_gemm_bf16x3_tile_variants_are_bit_identical(lib, M, N, K):
     a, b = split_paired(A), split_paired(B)
     outs = {}
     try:
-        for code in (11, 21, 23, 24):
-            lib.dic_debug_force_staged_gemm(code)
+        for code in (11, 21, 23, 24, 2477):
+            lib.dic_debug_force_staged_gemm(77 if code == 2477 else 76)
+            lib.dic_debug_force_staged_gemm(24 if code == 2477 else code)
             for rep in range(3):               # the persistent kernel's hand-offs are timing dependent: repeat
                 Cm = torch.full((M, N), float("nan"), device=DEV)
                 check(lib.dic_gemm_bf16x3_paired(M, N, K, ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(b[0]), ptr(b[1]), ptr(b[2]),
@@ -255,9 +257,62 @@ def test_gemm_bf16x3_tile_variants_are_bit_identical(lib, M, N, K):
                     assert torch.equal(outs[code], Cm), f"code {code}: repetition {rep} differs"
                 outs[code] = Cm
     finally:
+        lib.dic_debug_force_staged_gemm(76)
         lib.dic_debug_force_staged_gemm(20)
-    for code in (21, 23, 24):
+    for code in (21, 23, 24, 2477):
         assert torch.equal(outs[11], outs[code]), f"tile variant {code} differs from the 64x64 kernel"
     ref = A.double() @ B.double().t()
     col = ref.abs().max(dim=0).values + 1e-30
     assert float(((outs[24].double() - ref).abs() / col).max()) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,CO", [(3, 64, 128), (5, 32, 256), (40, 96, 128), (64, 256, 256)])
+def test_conv3x3_halo_kernel_vs_fp64_and_gather(lib, B, Cin, CO):
+    """3x3 / stride 1 / pad 1 convolution of 14x14 maps (ResNet layer 3) on the LDS-halo kernel (csrc/gemm_bf3.hip,
+    conv3x3_bf3_halo_kernel): output and train-mode BatchNorm partial sums against an fp64 convolution, with the im2col gather
+    kernel's own error as the yardstick (chunk-major instead of tap-major summation: same products, not bit-identical).
+    Covers a ragged last tile (588 and 980 output pixels), tiles that span two and three images, one and eight channel chunks,
+    several tiles per workgroup, and repeats each launch (the kernel's DMA hand-offs are timing dependent)."""
+    import torch.nn.functional as F
+    H = 14
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    w = (torch.randn(CO, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+
+    def split(x2d):
+        R, K = x2d.shape
+        out = [torch.empty((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3)]
+        check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+        return out
+
+    xp, wp = split(x.view(-1, Cin)), split(w.view(CO, -1))
+    planes = lambda ps: (C.c_void_p * 3)(*[t.data_ptr() for t in ps])                    # noqa: E731
+    M = B * H * H
+    global TAIL
+    if TAIL is None:
+        TAIL = torch.empty(256 * 64 * 64, device=DEV)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, CO)
+    scale = float(ref.abs().max())
+    res = {}
+    try:
+        for code in (75, 74):                                   # gather kernels, halo kernel
+            lib.dic_debug_force_staged_gemm(code)
+            for rep in range(3):
+                y = torch.full((M, CO), float("nan"), device=DEV)
+                part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+                mt = C.c_int(0)
+                check(lib.dic_debug_conv_bf3(planes(xp), B, H, H, Cin, planes(wp), CO, 3, 1, 1, ptr(y), ptr(part), C.byref(mt), ptr(TAIL),
+                                             stream_ptr()), "dic_debug_conv_bf3")
+                torch.cuda.synchronize()
+                assert torch.isfinite(y).all()
+                if code in res:
+                    assert torch.equal(res[code][0], y), f"code {code}: repetition {rep} differs"
+                res[code] = (y, part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu())
+    finally:
+        lib.dic_debug_force_staged_gemm(78)
+    err = {c: float((res[c][0].double().cpu() - ref).abs().max()) / scale for c in res}
+    assert err[74] <= 2.0 * err[75] + 1e-6, err
+    for c in res:
+        assert torch.allclose(res[c][1][0], ref.sum(0), rtol=1e-4, atol=1e-3 * scale), c
+        assert torch.allclose(res[c][1][1], (ref * ref).sum(0), rtol=1e-4, atol=1e-3 * scale), c
