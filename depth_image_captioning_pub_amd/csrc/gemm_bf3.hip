@@ -1025,7 +1025,7 @@ static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide vari
 static int g_bf3_persist_grid = 256;   // persistent kernel: workgroups (one per CU)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the LDS-halo kernel: 0 = off (code 75), 1 = from 128 tiles (78, default), 2 = always (74)
-static int g_bf3_persist_policy = 3;   // benchmarking (codes 70..73): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = by CU fill
+static int g_bf3_persist_policy = 4;   // benchmarking (codes 70..73, 79): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0; // benchmarking (codes 60..63): 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 template <int AK, int TM, int TN>
@@ -1042,6 +1042,7 @@ void gemm_bf3_force_tile(int code) {
   if (code >= 50 && code <= 53) { g_bf3_ablate = code - 50; return; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return; }
   if (code >= 70 && code <= 73) { g_bf3_persist_policy = code - 70; return; }
+  if (code == 79) { g_bf3_persist_policy = 4; return; }
   if (code == 74 || code == 75 || code == 78) { g_bf3_halo = code == 74 ? 2 : code == 78 ? 1 : 0; return; }
   if (code == 76 || code == 77) { g_bf3_ws = code == 76; return; }
   g_bf3_force = code;
@@ -1083,7 +1084,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (g_bf3_persist_policy == 1) persist = p.K <= 64 && t22 >= 1024;
     else if (g_bf3_persist_policy == 2) persist = (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
     else if (g_bf3_persist_policy >= 3)     // warp-specialised form (scripts/bench_bf3_pipe.py at batch 64 and 256): wins wherever the
-      persist = (p.A.kind == OPK_ROWK && t22 >= 192 && (fill22 >= 0.85 || (fill22 >= 0.75 && p.K >= 512))) ||      // tiles fill the CUs
+      persist = ((p.A.kind == OPK_ROWK || g_bf3_persist_policy >= 4) && t22 >= 192 && (fill22 >= 0.85 || (fill22 >= 0.75 && p.K >= 512))) ||      // tiles fill the CUs
                 (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
   }
   if (g_bf3_force == 24) persist = persist_ok;

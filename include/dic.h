@@ -318,7 +318,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   23 24        ... forced to the deep-pipelined 128x128 kernel / its persistent form (wherever its epilogue applies)
  *   42 43        ring depth 2 / 3 of the 128-wide bf16x3 variants
  *   50 51 52 53  ablations of the kernel selected by 11 / 23 / the halo kernel: full / no DMA in the loop / ... (scripts/bench_bf3_*ablate*.py)
- *   70..73       persistent kernel by policy: never / K <= 64 / + K <= 256 on >= 3072-tile grids / by CU fill (default)
+ *   70..73 79    persistent kernel by policy: never / K <= 64 / + K <= 256 on >= 3072-tile grids / 1x1 convolutions by CU fill / + gathered convolutions (default)
  *   76 77        persistent kernel warp-specialised, 4 compute + 4 DMA waves (default) / DMA issued by the computing waves
  *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
  *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
