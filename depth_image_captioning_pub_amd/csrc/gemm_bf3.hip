@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(256) gemm_bf3_persist_kernel(const Bf3Params p
 // (scripts/bench_bf3_pipe_ablate.py) - a global_load_lds that cannot issue (address arithmetic, M0 set-up, a full
 // vector-memory queue) blocks the MFMAs queued behind it in the same wave.  A producer wave that blocks costs nothing.
 // Two waves per SIMD, so the kernel has to fit 256 registers; the stores of a seam and the DMA no longer share a vmcnt.
-template <int AK>
+template <int AK, int ABL = 0>      // ABL (measurement only): 1 = the producer waves issue nothing inside the loop
 __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128, NST = 3;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       if (g + 2 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
-      if (g + NST < total) prefetch(smem + st * STAGE);
+      if (ABL == 0 && g + NST < total) prefetch(smem + st * STAGE);
       st = st == NST - 1 ? 0 : st + 1;
     }
     return;
@@ -761,6 +761,157 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 #undef DIC_PIPE_READ_B
 #undef DIC_PIPE_PIN
 #undef DIC_PIPE_MFMA
+}
+
+// 256x128 form of the warp-specialised persistent kernel (MEASURED, NOT USED BY DEFAULT: 203 -> 216 us on 50176x256x1024,
+// 689 -> 740 us on 4096^3), for grids deep enough to fill the CUs with half as many tiles: eight computing waves (4 x 2, 64x64 each) + four producer waves = three waves per SIMD, 168 registers each.
+// Operand bytes per MFMA drop by a quarter (72 KB per K tile for twice the MFMAs), which is what the 128x128 form still waits
+// for (scripts/bench_bf3_ws_ablate.py: 3100-3900 cycles per K tile against 2400-2600 without any DMA).  Two ring stages of
+// 72 KB; B fragments are single-buffered (the second computing wave of the SIMD covers their latency), A fragments stay
+// double-buffered by k-step.  BatchNorm partials per 64-row wave tile: [4*mtiles][2][N].  Bit-identical to gemm_bf3_kernel.
+template <int AK>
+__global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Params p) {
+  constexpr int BM = 256, BN = 128, NST = 2;
+  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
+  constexpr int NDMA = 3 * (BM / 64) + 3 * (BN / 64);             // 18 DMA instructions per producer wave and K tile
+  __shared__ __align__(1024) unsigned short smem[NST * STAGE];     // 144 KB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = (p.K + BK3 - 1) / BK3;
+  const int T = p.mtiles * p.ntiles, G = gridDim.x;
+  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
+  const int total = ntl * nkt;
+
+  if (wave >= 8) {
+    // ---------------- producer waves (8..11 -> row groups 0..3 of the loaders)
+    Bf3Loader<AK, BM> la;
+    Bf3Loader<OPK_ROWK, BN> lbld;
+    int pj = 0, pkt = 0;
+    {
+      const int t = xcd_remap(blockIdx.x, T);
+      la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+      lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+    }
+    auto prefetch = [&](unsigned short* stage) {
+      la.issue(pkt * BK3, stage);
+      lbld.issue(pkt * BK3, stage + AOPER);
+      if (++pkt == nkt) {
+        pkt = 0; ++pj;
+        if (pj < ntl) {
+          const int t = xcd_remap(blockIdx.x + pj * G, T);
+          la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+          lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+        }
+      }
+    };
+    prefetch(smem);
+    if (total > 1) { prefetch(smem + STAGE); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
+    for (int g = 0; g < total; ++g) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // slot g+1 (issued a whole K tile ago) has landed
+      __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage g & 1
+      if (g + NST < total) prefetch(smem + (g & 1) * STAGE);
+    }
+    return;
+  }
+
+  // ---------------- consumer waves
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
+  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+  u32x4 fa[2][2][3], fb[2][3];                     // A: [k-step buffer][tile][plane];  B: [tile][plane]
+#define DIC_W_READ_A(KS_, SB_)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
+      bf3_lds_read(fa[KS_][i][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)(i * 32 * 64) + pos[KS_]);
+#define DIC_W_READ_B(KS_, SB_)                                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
+      bf3_lds_read(fb[j][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)(j * 32 * 64) + pos[KS_]);
+#define DIC_W_PIN(KS_)                                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[i][pl])); }
+#define DIC_W_MFMA(KS_, PA_, PB_)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
+                                                          __builtin_bit_cast(bf16x8, fb[j][PB_]), acc[i][j], 0, 0, 0);
+#define DIC_W_MFMA_ALL(KS_)                                                                                          \
+  DIC_W_MFMA(KS_, 2, 0) DIC_W_MFMA(KS_, 0, 2) DIC_W_MFMA(KS_, 1, 1) DIC_W_MFMA(KS_, 1, 0) DIC_W_MFMA(KS_, 0, 1) DIC_W_MFMA(KS_, 0, 0)
+  __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
+  DIC_W_READ_A(0, sbase0)
+  int g = 0;
+  for (int j = 0; j < ntl; ++j) {
+    for (int kt = 0; kt < nkt; ++kt, ++g) {
+      const unsigned sb = sbase0 + (unsigned)((g & 1) * STAGE) * 2u, sbn = sbase0 + (unsigned)(((g + 1) & 1) * STAGE) * 2u;
+      // k-step 0: its A fragments were requested one k-step ago; request its B fragments and k-step 1's A fragments
+      DIC_W_READ_B(0, sb) DIC_W_READ_A(1, sb)
+      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      DIC_W_PIN(0)
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_W_MFMA_ALL(0)
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 1: B fragments (same registers: the MFMAs above have been issued), then every read of this stage is done
+      DIC_W_READ_B(1, sb)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DIC_W_PIN(1)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_W_MFMA(1, 2, 0)
+      if (g + 1 < total) { DIC_W_READ_A(0, sbn) }
+      DIC_W_MFMA(1, 0, 2) DIC_W_MFMA(1, 1, 1) DIC_W_MFMA(1, 1, 0) DIC_W_MFMA(1, 0, 1) DIC_W_MFMA(1, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- seam: store the tile
+    const int t = xcd_remap(blockIdx.x + j * G, T);
+    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
+              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
+          cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
+          acc[i][jj][r] = 0.f;
+        }
+      }
+    if (p.ep.stats) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
+        const int n = n0 + jj * 32;
+        if (lane < 32 && n < p.N && tm * BM + wm * 64 < p.M) {      // (wave tiles entirely past M have no row in the table)
+          p.ep.stats[((long long)(tm * 4 + wm) * 2 + 0) * p.N + n] = a;
+          p.ep.stats[((long long)(tm * 4 + wm) * 2 + 1) * p.N + n] = b;
+        }
+      }
+    }
+  }
+#undef DIC_W_READ_A
+#undef DIC_W_READ_B
+#undef DIC_W_PIN
+#undef DIC_W_MFMA
+#undef DIC_W_MFMA_ALL
 }
 
 // 3x3 / stride-1 / pad-1 convolution on 14x14 maps (ResNet layer 3: 36 of the 50 3x3 convolutions) with the input tile's HALO
@@ -1023,6 +1174,8 @@ void gemm_bf3_force_tile(int code);
 
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
 static int g_bf3_persist_grid = 256;   // persistent kernel: workgroups (one per CU)
+static int g_bf3_ws256 = 0;            // codes 80 / 81: 256x128 form of the warp-specialised kernel by policy on / off (default off: measured
+                                       // 4-7 % SLOWER than the 128x128 form on every shape, scripts/bench_bf3_pipe.py; 26 forces it)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the LDS-halo kernel: 0 = off (code 75), 1 = from 128 tiles (78, default), 2 = always (74)
 static int g_bf3_persist_policy = 4;   // benchmarking (codes 70..73, 79): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
@@ -1045,6 +1198,7 @@ void gemm_bf3_force_tile(int code) {
   if (code == 79) { g_bf3_persist_policy = 4; return; }
   if (code == 74 || code == 75 || code == 78) { g_bf3_halo = code == 74 ? 2 : code == 78 ? 1 : 0; return; }
   if (code == 76 || code == 77) { g_bf3_ws = code == 76; return; }
+  if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return; }
   g_bf3_force = code;
 }
 
@@ -1087,14 +1241,20 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       persist = ((p.A.kind == OPK_ROWK || g_bf3_persist_policy >= 4) && t22 >= 192 && (fill22 >= 0.85 || (fill22 >= 0.75 && p.K >= 512))) ||      // tiles fill the CUs
                 (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
   }
-  if (g_bf3_force == 24) persist = persist_ok;
+  if (g_bf3_force == 24 || g_bf3_force == 26) persist = persist_ok;
+  // 256x128 form: half as many tiles must still fill the CUs
+  const long long t42 = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128);
+  const int rounds42 = (int)((t42 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
+  const double fill42 = (double)t42 / ((double)rounds42 * g_bf3_persist_grid);
+  bool ws256 = g_bf3_force == 26 && persist_ok;
+  if (g_bf3_force == 0 && g_bf3_ws256 != 0 && persist && g_bf3_ws && t42 >= 512 && fill42 >= 0.75 && fill42 >= fill22 - 0.03 && p.K >= 128) ws256 = true;
   // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
   const ConvGeom& cg = p.A.g;
   const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
                     cg.stride == 1 && cg.pad == 1 && cg.H == 14 && cg.W == 14 && cg.nchw == 0 && cg.C % BK3 == 0 &&
                     p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
   if (halo) persist = true;
-  if (g_bf3_force == 24 || persist) { tmv = 2; tnv = 2; }
+  if (g_bf3_force == 24 || g_bf3_force == 26 || persist) { tmv = 2; tnv = 2; }
   const bool pipe = tmv == 2 && tnv == 2 && g_bf3_force != 22;       // 128x128 = the deep-pipelined kernel (22: the plain loop)
   persist = persist && pipe;
   p.mtiles = ceil_div(p.M, 64 * tmv); p.ntiles = ceil_div(p.N, 64 * tnv);
@@ -1126,12 +1286,20 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   const bool im = p.A.kind == OPK_IM2COL;
-  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
-  if (persist) {
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
+  if (persist && ws256 && !halo) {
+    p.mtiles = ceil_div(p.M, 256); p.ntiles = ceil_div(p.N, 128);
+    g_last_mtiles = ceil_div(p.M, 64);     // statistics rows per 64-row wave tile
+    const int T4 = p.mtiles * p.ntiles, grid = ceil_div(T4, ceil_div(T4, g_bf3_persist_grid));
+    if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_IM2COL>), dim3(grid), dim3(768), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK>), dim3(grid), dim3(768), 0, st, p);
+  } else if (persist) {
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
     const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
-    if (!halo && g_bf3_ws) {
+    if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) {
+      hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 1>), dim3(grid), dim3(512), 0, st, p);
+    } else if (!halo && g_bf3_ws) {
       if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
       else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
     } else if (halo && g_bf3_ablate == 1) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<1>, dim3(grid), dim3(512), 0, st, p);

@@ -315,7 +315,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
 /* Benchmarking / ablation switches (process-global, used by scripts/ only; results stay correct under every code):
  *   0 / 1        LDS-DMA kernels (default) / every exact-fp32 contraction on the register-staged kernel (v1)
  *   11 21 22 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / 128x128 (plain loop) / policy default
- *   23 24        ... forced to the deep-pipelined 128x128 kernel / its persistent form (wherever its epilogue applies)
+ *   23 24 26     ... forced to the deep-pipelined 128x128 kernel / its persistent form (wherever its epilogue applies) / the 256x128 form
+ *   80 81        256x128 persistent form by policy on / off (default: measured slower)
  *   42 43        ring depth 2 / 3 of the 128-wide bf16x3 variants
  *   50 51 52 53  ablations of the kernel selected by 11 / 23 / the halo kernel: full / no DMA in the loop / ... (scripts/bench_bf3_*ablate*.py)
  *   70..73 79    persistent kernel by policy: never / K <= 64 / + K <= 256 on >= 3072-tile grids / 1x1 convolutions by CU fill / + gathered convolutions (default)
