@@ -18,6 +18,9 @@ namespace dic {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK3 = 32;          // K tile in elements (64 B per plane row)
+#ifndef DIC_WS_A_AUX
+#define DIC_WS_A_AUX 0    // cache policy of the streamed A operand in the warp-specialised kernel (2 = nt measured within +-3 %: left at default)
+#endif
 
 __device__ __attribute__((aligned(256))) const unsigned short g_zero_line16[128] = {0};
 
@@ -127,6 +130,7 @@ struct Bf3Loader {
   }
 
   // img: this operand's [3][BR][32] bf16 image of one stage
+  template <int AUX = 0>      // AUX: cache-policy bits of the DMA (2 = nt, a streamed operand)
   __device__ __forceinline__ void issue(int k0, unsigned short* img) const {
     const int w = (threadIdx.x >> 6) & 3;
     int tap = 0, dpix = 0;
@@ -160,7 +164,7 @@ struct Bf3Loader {
         const unsigned short* src = ok ? p[pl] + off : g_zero_line16;
         unsigned short* dst = img + pl * BR * BK3 + ((n * 4 + w) * 16) * BK3;       // wave-uniform 1-KiB block
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, AUX);
       }
     }
   }
@@ -640,7 +644,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
     }
     auto prefetch = [&](unsigned short* stage) {
-      la.issue(pkt * BK3, stage);
+      la.template issue<DIC_WS_A_AUX>(pkt * BK3, stage);
       lbld.issue(pkt * BK3, stage + AOPER);
       if (++pkt == nkt) {
         pkt = 0; ++pj;
