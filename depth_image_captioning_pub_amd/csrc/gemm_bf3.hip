@@ -621,9 +621,9 @@ __global__ void __launch_bounds__(256) gemm_bf3_persist_kernel(const Bf3Params p
 // (scripts/bench_bf3_pipe_ablate.py) - a global_load_lds that cannot issue (address arithmetic, M0 set-up, a full
 // vector-memory queue) blocks the MFMAs queued behind it in the same wave.  A producer wave that blocks costs nothing.
 // Two waves per SIMD, so the kernel has to fit 256 registers; the stores of a seam and the DMA no longer share a vmcnt.
-template <int AK, int ABL = 0>      // ABL (measurement only): 1 = the producer waves issue nothing inside the loop
+template <int AK, int ABL = 0, int NST = 3>      // ABL (measurement only): 1 = the producer waves issue nothing inside the loop; NST: ring stages
 __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
-  constexpr int BM = 128, BN = 128, NST = 3;
+  constexpr int BM = 128, BN = 128;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];
 
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     int st = 0;
     for (int g = 0; g < total; ++g) {
       // before the consumers read slot g+1 (after this barrier) it must have landed; slot g+2 may stay in flight
-      if (g + 2 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
       if (ABL == 0 && g + NST < total) prefetch(smem + st * STAGE);
@@ -1301,7 +1301,9 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
     const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
-    if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) {
+    if (!halo && g_bf3_ws && g_bf3_ablate == 2 && !im) {
+      hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 2>), dim3(grid), dim3(512), 0, st, p);
+    } else if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) {
       hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 1>), dim3(grid), dim3(512), 0, st, p);
     } else if (!halo && g_bf3_ws) {
       if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);

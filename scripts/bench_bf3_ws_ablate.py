@@ -25,7 +25,7 @@ for (M, N, K) in [(4096, 4096, 4096), (50176, 256, 1024), (50176, 1024, 256), (1
     lib.dic_debug_force_staged_gemm(24)
     T = -(-M // 128) * (N // 128); per_wg = -(-T // 256)
     slots = per_wg * (K // 32)
-    for abl, name in ((0, "full"), (1, "no DMA in loop")):
+    for abl, name in ((0, "full"), (2, "2-stage ring"), (1, "no DMA in loop")):
         lib.dic_debug_force_staged_gemm(50 + abl)
         t = timeit(f)
         print(f"M={M:6d} N={N:5d} K={K:5d} {name:16s}: {t:8.1f} us = {t / slots * 2400:6.0f} nominal cycles per K tile of the busiest workgroup ({per_wg} tiles), {2*M*N*K*6/t/1e6/2500:.3f} of bf16 peak", flush=True)
