@@ -73,7 +73,7 @@ def profile_step(trainer, args_step):
             a, tcode = (k - 2000) // 10, (k - 2000) % 10
             if tcode >= 4:                                  # 128x128: deep-pipelined / persistent (warp-specialised) / LDS-halo 3x3
                 name, rname = {4: (f"gemm_bf3_pipe_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_pipe_kernel<{a}, "),
-                               5: (f"gemm_bf3_persist_ws_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws_kernel<{a}>"),
+                               5: (f"gemm_bf3_persist_ws_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws_kernel<{a}"),
                                6: ("conv3x3_bf3_halo_kernel", "conv3x3_bf3_halo_kernel<0>")}[tcode]
                 rows.append({"kernel": name, "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i],
                              "peak": PEAK_BF16X3_TFLOPS})
