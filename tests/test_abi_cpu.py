@@ -24,3 +24,15 @@ def test_loader_fails_loudly_when_library_missing(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("missing library must raise")
+
+
+def test_unknown_debug_switch_is_rejected():
+    """The benchmarking switches are process-global state (include/dic.h): an unknown code must be an error, not a silent
+    change of some other switch (round 2: code 182 fell through to the exact-fp32 kernel selector).  No GPU call involved."""
+    lib = ctypes.CDLL(build.build())
+    lib.dic_last_error.restype = ctypes.c_char_p
+    for code in (9999, 182, -5, 29):
+        assert lib.dic_debug_force_staged_gemm(code) != 0, code
+        assert b"unknown" in lib.dic_last_error()
+    for code in (20, 78, 76, 73, 79):          # the defaults of the bf16x3 policy switches: accepted, no effect on results
+        assert lib.dic_debug_force_staged_gemm(code) == 0, code
