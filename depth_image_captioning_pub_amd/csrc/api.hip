@@ -43,7 +43,7 @@ int dic_debug_force_staged_gemm(int on) {
   if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement   // decoder forward: per-step launches / persistent loop
   if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
-  if (on == 11 || on == 21 || on == 22 || on == 23 || on == 24 || on == 26 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 53) || (on >= 60 && on <= 63) || (on >= 70 && on <= 81)) gemm_bf3_force_tile(on == 20 ? 0 : on);
+  if (on == 11 || on == 21 || on == 22 || on == 23 || on == 24 || on == 26 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 53) || (on >= 60 && on <= 63) || (on >= 70 && on <= 89)) gemm_bf3_force_tile(on == 20 ? 0 : on);
   else if (on >= 0 && on <= 13) gemm_force_v1(on);
   else DIC_REQUIRE(false, "debug switch: unknown code");
   return 0;

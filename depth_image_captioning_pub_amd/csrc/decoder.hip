@@ -1065,6 +1065,19 @@ static int check_common(const dic_decoder_weights* w, int V, int B, const void* 
 
 extern "C" {
 
+int dic_decoder_inspect(const void* workspace, size_t workspace_bytes, int B, int Tmax, int V, int n_packed, int cells, int which,
+                        float* out, long long* n_out, void* stream) {
+  DIC_REQUIRE(workspace && B > 0 && Tmax > 0 && (which == 1 || which == 2) && (cells == kL || cells == kLc), "decoder_inspect: bad arguments");
+  bool ov = false;
+  DecoderWs ws = decoder_carve(const_cast<void*>(workspace), workspace_bytes, B, Tmax, V, n_packed, &ov);
+  DIC_REQUIRE(!ov, "decoder_inspect: workspace too small");
+  const long long n = which == 1 ? (long long)B * cells * kA : (long long)B * Tmax * kA;
+  if (n_out) *n_out = n;
+  if (!out) return DIC_OK;
+  DIC_CHECK_HIP(hipMemcpyAsync(out, which == 1 ? ws.P : ws.Qall, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DIC_OK;
+}
+
 size_t dic_decoder_workspace_bytes(int B, int Tmax, int V, int n_packed) {
   bool ov;
   return decoder_carve(nullptr, 0, B, Tmax, V, n_packed, &ov).bytes;

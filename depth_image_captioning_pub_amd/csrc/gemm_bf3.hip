@@ -1177,7 +1177,9 @@ static int g_bf3_force = 0;     // benchmarking: 11 / 21 / 22 force the 64x64 / 
 void gemm_bf3_force_tile(int code);
 
 static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
-static int g_bf3_persist_grid = 256;   // persistent kernel: workgroups (one per CU)
+static int g_bf3_persist_grid = 224;   // persistent kernels: at most this many workgroups (one per CU).  224 rather than 256: same time per launch
+                                       // (operand delivery, not CU count, bounds them) and the main stream's short kernels find free CUs: pipelined step
+                                       // 14.28 -> 14.02 ms; codes 82..89 = 256, 240, ... 144
 static int g_bf3_ws256 = 0;            // codes 80 / 81: 256x128 form of the warp-specialised kernel by policy on / off (default off: measured
                                        // 4-7 % SLOWER than the 128x128 form on every shape, scripts/bench_bf3_pipe.py; 26 forces it)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
@@ -1203,6 +1205,7 @@ void gemm_bf3_force_tile(int code) {
   if (code == 74 || code == 75 || code == 78) { g_bf3_halo = code == 74 ? 2 : code == 78 ? 1 : 0; return; }
   if (code == 76 || code == 77) { g_bf3_ws = code == 76; return; }
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return; }
+  if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return; }      // persistent grids of at most 256, 240, ... 144 workgroups
   g_bf3_force = code;
 }
 

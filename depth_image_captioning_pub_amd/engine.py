@@ -398,6 +398,8 @@ class CaptionTrainer:
             self.apply_update()
         self._mark("adamw")
         self.last = {"logits": logits, "alphas": alphas, "features": feats, "depth_features": fdep}
+        if self.keep_outputs:
+            self.last["decoder_tape"] = tape           # parity tests: native.decoder_attention_relu_mask(tape)
         return loss
 
     def apply_update(self) -> None:

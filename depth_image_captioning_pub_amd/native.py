@@ -75,6 +75,23 @@ class DecoderTape:
     cells: int = 196
 
 
+def decoder_attention_relu_mask(tape: DecoderTape) -> torch.Tensor:
+    """dic_decoder_inspect: which units of the attention ReLU passed in the forward that produced `tape`, bool
+    [B, Tmax, cells, D_ATT] (rows of finished captions are meaningless).  For the parity tests' decision replay."""
+    lib = _lib.load()
+    B, T = len(tape.dec_len), tape.tmax
+    dev = tape.workspace.device
+    out = []
+    for which, shape in ((1, (B, 1, tape.cells, D_ATT)), (2, (B, T, 1, D_ATT))):
+        t = torch.empty(shape, dtype=torch.float32, device=dev)
+        n = C.c_longlong(0)
+        check(lib.dic_decoder_inspect(ptr(tape.workspace), C.c_size_t(tape.workspace.numel()), B, T, tape.vocab, tape.n_packed,
+                                      tape.cells, which, ptr(t), C.byref(n), stream_ptr()), "dic_decoder_inspect")
+        assert n.value == t.numel()
+        out.append(t)
+    return (out[0] + out[1]) > 0
+
+
 def batch_sizes_of(dec_len: Sequence[int]) -> List[int]:
     return [sum(1 for l in dec_len if l > t) for t in range(max(dec_len))]
 

@@ -208,6 +208,12 @@ int dic_depth_encoder_bwd_map(const dic_depth_encoder_weights* w, const float* d
  * *n_out (nullable) receives the element count; out == NULL only queries it.  Device-to-device copy on `stream`. */
 int dic_depth_encoder_inspect(const void* workspace, size_t workspace_bytes, int B, int H, int W, int which, void* out,
                               long long* n_out, void* stream);
+/* The same for the decoder: the two tensors that decide the attention ReLU of the last dic_decoder_fwd* call on `workspace`
+ * (attention.py:84-87; the only other discontinuity of the step):  which 1: P = W_z F + b_z, float [B,cells,128];
+ * which 2: q_t = W_h h_t + b_h for every step, float [B,Tmax,128] (rows of finished captions hold stale values).  Unit
+ * (b,t,l,a) passes <=> P[b,l,a] + q[b,t,a] > 0 in fp32 - forward and backward kernels both evaluate exactly this sum. */
+int dic_decoder_inspect(const void* workspace, size_t workspace_bytes, int B, int Tmax, int V, int n_packed, int cells, int which,
+                        float* out, long long* n_out, void* stream);
 
 /* ---- RGB encoder: CNNEncoder_Atten (Base_caption_model/base_caption_models.py:18-45) = torchvision
  *      ResNet-152 (Bottleneck v1.5; blocks = {3,8,36,3}) minus fc, avgpool -> AdaptiveAvgPool2d(14).
@@ -317,6 +323,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   11 21 22 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / 128x128 (plain loop) / policy default
  *   23 24 26     ... forced to the deep-pipelined 128x128 kernel / its persistent form (wherever its epilogue applies) / the 256x128 form
  *   80 81        256x128 persistent form by policy on / off (default: measured slower)
+ *   82..89       persistent kernels use at most 256 / 240 / 224 (default) / ... / 144 workgroups
  *   42 43        ring depth 2 / 3 of the 128-wide bf16x3 variants
  *   50 51 52 53  ablations of the kernel selected by 11 / 23 / the halo kernel: full / no DMA in the loop / ... (scripts/bench_bf3_*ablate*.py)
  *   70..73 79    persistent kernel by policy: never / K <= 64 / + K <= 256 on >= 3072-tile grids / 1x1 convolutions by CU fill / + gathered convolutions (default)

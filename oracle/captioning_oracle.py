@@ -23,44 +23,32 @@ LAMBDA_ALPHA = 0.7     # `lam`  (Depth_caption_model/depth_train.py:25)
 # --------------------------------------------------------------------------
 # attention  (Captioning_models/attention.py)
 # --------------------------------------------------------------------------
-def attention_scores(w: Dict[str, Tensor], feats: Tensor, h: Tensor, prefix: str = "attention.", ties: Optional[list] = None) -> Tensor:
+def attention_scores(w: Dict[str, Tensor], feats: Tensor, h: Tensor, prefix: str = "attention.", mask: Optional[Tensor] = None,
+                     report: Optional[dict] = None) -> Tensor:
     """e[b,l] = w . relu(Wz F[b,l] + bz + Wh h[b] + bh) + b   (attention.py:84-87).
-    ties (parity tests only): receives (pre-activation, ReLU output with its gradient retained, feats, h) of this call for
-    attention_relu_tie_bound."""
+    mask (parity tests only, bool [nb,L,A]): replay THESE ReLU decisions instead of taking them afresh - a unit within
+    rounding of the kink may pass in one correct fp32 evaluation and not in another, and each such flip moves the small
+    gradients of the attention matrices (and, through dF, of the depth encoder) by the unit's whole term.  `report` receives
+    how many decisions differ from this evaluation's own and the largest |pre-activation| among them (the tie evidence)."""
     att1 = F.linear(feats, w[prefix + "encoder_att.weight"], w[prefix + "encoder_att.bias"])
     att2 = F.linear(h, w[prefix + "decoder_att.weight"], w[prefix + "decoder_att.bias"])
     pre = att1 + att2.unsqueeze(1)
-    act = torch.relu(pre)
-    if ties is not None:
-        act.retain_grad()
-        ties.append((pre.detach(), act, feats.detach(), h.detach()))
+    if mask is None:
+        act = torch.relu(pre)
+    else:
+        act = torch.where(mask, pre, torch.zeros_like(pre))
+        if report is not None:
+            diff = mask != (pre.detach() > 0)
+            report["att_relu"] = (report.get("att_relu", (0, 0.0))[0] + int(diff.sum()),
+                                  max(report.get("att_relu", (0, 0.0))[1], float((pre.detach().abs() * diff).max()) if bool(diff.any()) else 0.0))
     e = F.linear(act, w[prefix + "full_att.weight"], w[prefix + "full_att.bias"]).squeeze(2)
     return e
 
 
-def attention_relu_tie_bound(ties: list, tau: float, prefix: str = "attention.") -> Dict[str, Tensor]:
-    """After backward: for the four parameters below the attention ReLU, sum_u |dL/d act_u| * |input_u| over the units u whose
-    pre-activation lies within tau of zero.  An evaluation in another arithmetic (fp32 kernels, another summation order) may
-    take the other branch of exactly those units, and each such flip moves the gradient by that unit's whole term: the bound
-    is how far two CORRECT evaluations of the step can differ in these gradients beyond round-off."""
-    out: Dict[str, Tensor] = {}
-    for pre, act, feats, h in ties:
-        near = (pre.abs() < tau).nonzero()                       # [n, 3] = (b, cell, unit)
-        if near.numel() == 0:
-            continue
-        g = act.grad[near[:, 0], near[:, 1], near[:, 2]].abs()   # [n]
-        A = pre.shape[2]
-        for name, contrib in ((prefix + "encoder_att.weight", g.unsqueeze(1) * feats[near[:, 0], near[:, 1]].abs()),
-                              (prefix + "decoder_att.weight", g.unsqueeze(1) * h[near[:, 0]].abs()),
-                              (prefix + "encoder_att.bias", g), (prefix + "decoder_att.bias", g)):
-            shape = (A,) + tuple(contrib.shape[1:])
-            out.setdefault(name, torch.zeros(shape, dtype=contrib.dtype)).index_add_(0, near[:, 2], contrib)
-    return out
-
-
-def soft_attention(w: Dict[str, Tensor], feats: Tensor, h: Tensor, prefix: str = "attention.", ties: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+def soft_attention(w: Dict[str, Tensor], feats: Tensor, h: Tensor, prefix: str = "attention.", mask: Optional[Tensor] = None,
+                   report: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
     """Soft_Attention.forward (attention.py:81-95): alpha = softmax_L(e); ctx = sum_l alpha_l F_l."""
-    alpha = attention_scores(w, feats, h, prefix, ties).softmax(dim=1)
+    alpha = attention_scores(w, feats, h, prefix, mask, report).softmax(dim=1)
     ctx = (feats * alpha.unsqueeze(2)).sum(dim=1)
     return ctx, alpha
 
@@ -115,7 +103,7 @@ def batch_sizes_of(dec_lengths: Sequence[int]) -> List[int]:
 def decoder_forward(w: Dict[str, Tensor], feats_rgb: Tensor, feats_depth: Tensor, captions: Tensor,
                     lengths: Sequence[int], drop_mult: Optional[Tensor] = None,
                     hard_u: Optional[Tensor] = None, temp: Optional[Tensor] = None,
-                    hard_eval: bool = False, ties: Optional[list] = None):
+                    hard_eval: bool = False, att_masks: Optional[Tensor] = None, report: Optional[dict] = None):
     """CD_RNNDecoderWith{Soft,Hard}Attention.forward / eval_forward
     (depth_models.py:153-207, 580-634, 637-689).
 
@@ -136,7 +124,7 @@ def decoder_forward(w: Dict[str, Tensor], feats_rgb: Tensor, feats_depth: Tensor
     for t in range(tmax):                                               # :179
         nb = sum(1 for l in dec_len if l > t)                           # :182
         if hard_u is None:
-            ctx, alpha = soft_attention(w, fused[:nb], h[:nb], ties=ties)
+            ctx, alpha = soft_attention(w, fused[:nb], h[:nb], mask=None if att_masks is None else att_masks[:nb, t], report=report)
         elif hard_eval:
             ctx, alpha = hard_attention_sample(w, fused[:nb], h[:nb], hard_u[t, :nb])
             alpha = alpha.to(fused.dtype)
@@ -353,9 +341,10 @@ def train_step_soft(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_stat
                     feats_rgb: Tensor, depth_map: Tensor, captions: Tensor, lengths: Sequence[int],
                     drop_mult: Optional[Tensor], decisions: Optional[Dict[str, Tensor]] = None,
                     report: Optional[dict] = None, hard_u: Optional[Tensor] = None, temp: Optional[Tensor] = None,
-                    att_tie_tau: Optional[float] = None):
+                    att_masks: Optional[Tensor] = None):
     """Forward + loss + backward.  Returns (loss, packed_logits, alphas, grads_dec, grads_enc).
-    att_tie_tau (with `report`): report["att_tie_bound"] = attention_relu_tie_bound(tau) of this step (soft attention).
+    att_masks (bool [B,Tmax,196,A], soft attention): replay the attention ReLU decisions (attention_scores); `report`
+    receives the tie evidence under "att_relu".
     hard_u [Tmax,B,196] + temp: the depth-HARD step of train_Cdepth_hard (depth_train.py:500-560): Gumbel-softmax
     attention with the uniform draws as explicit input, loss = cross-entropy only (:530-532).
     decisions: replay the depth encoder's ReLU / max-pool selections (depth_encoder_forward_replay; `report` receives
@@ -368,13 +357,10 @@ def train_step_soft(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_stat
         fd, rep = depth_encoder_forward_replay(ew, enc_state, depth_map.detach(), decisions)
         if report is not None:
             report.update(rep)
-    ties = [] if (att_tie_tau is not None and report is not None and hard_u is None) else None
-    packed, bsz, alphas = decoder_forward(dw, feats_rgb, fd, captions, lengths, drop_mult, hard_u=hard_u, temp=temp, ties=ties)
+    packed, bsz, alphas = decoder_forward(dw, feats_rgb, fd, captions, lengths, drop_mult, hard_u=hard_u, temp=temp,
+                                          att_masks=att_masks, report=report)
     loss = caption_loss(packed, pack_targets(captions, lengths), None if hard_u is not None else alphas)   # :210-216 / :530
     loss.backward()                                                                # :219
-    if ties is not None:
-        report["att_tie_bound"] = attention_relu_tie_bound(ties, att_tie_tau)
-        report["att_tie_units"] = sum(int((pre.abs() < att_tie_tau).sum()) for pre, _, _, _ in ties)
     gd = {k: v.grad for k, v in dw.items()}
     ge = {k: v.grad for k, v in ew.items()}
     return loss.detach(), packed.detach(), alphas.detach(), gd, ge
