@@ -727,6 +727,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     const int t = xcd_remap(blockIdx.x + j * G, T);
     const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
     const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    const bool plain = !p.ep.bias && p.ep.act == ACT_NONE && !p.ep.accumulate;
     const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
     float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
 #pragma unroll
@@ -734,7 +735,26 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
-        if (full) {
+        if (!plain) {      // bias / activation / accumulate (finalize_store's order): the stored value replaces the accumulator
+          const int n = n0 + jj * 32;
+          const float bcol = (p.ep.bias && n < p.N) ? p.ep.bias[n] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][jj][r] + bcol;
+            if (p.ep.act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.ep.act == ACT_SIGMOID) v = sigmoidf_(v);
+            else if (p.ep.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            const bool in = m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n < p.N;
+            float* dst = col + (long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc;
+            if (in) {
+              if (p.ep.accumulate) v += *dst;
+              *dst = v;
+            } else {
+              v = 0.f;       // outside the matrix: nothing stored, nothing in the statistics
+            }
+            acc[i][jj][r] = v;
+          }
+        } else if (full) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
         } else {
@@ -1235,8 +1255,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // Persistent 128x128 kernel: plain-store epilogue without bias, at least two K tiles.  Policy (scripts/bench_bf3_pipe.py):
   // it wins where a tile is only a few K tiles long and the grid is many rounds deep - the 1x1 expansions 64 -> 256
   // (-12 % per launch at batch 64, -20 % at batch 256), and at batch-256 scale also 128 -> 512 and 256 -> 1024.
-  const bool persist_ok = splitk <= 1 && !p.ep.bias && !p.ep.accumulate && !p.ep.row_map && !p.ep.C2 && p.ep.act == ACT_NONE &&
-                          p.K > BK3 && p.N % 128 == 0;
+  const bool plain_ep = !p.ep.bias && !p.ep.accumulate && p.ep.act == ACT_NONE;      // what the halo / 256x128 / computing-wave-DMA forms store
+  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && p.N % 128 == 0 && (plain_ep || g_bf3_ws);
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
   const double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
@@ -1253,11 +1273,11 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   const long long t42 = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128);
   const int rounds42 = (int)((t42 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
   const double fill42 = (double)t42 / ((double)rounds42 * g_bf3_persist_grid);
-  bool ws256 = g_bf3_force == 26 && persist_ok;
-  if (g_bf3_force == 0 && g_bf3_ws256 != 0 && persist && g_bf3_ws && t42 >= 512 && fill42 >= 0.75 && fill42 >= fill22 - 0.03 && p.K >= 128) ws256 = true;
+  bool ws256 = g_bf3_force == 26 && persist_ok && plain_ep;
+  if (g_bf3_force == 0 && g_bf3_ws256 != 0 && persist && g_bf3_ws && plain_ep && t42 >= 512 && fill42 >= 0.75 && fill42 >= fill22 - 0.03 && p.K >= 128) ws256 = true;
   // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
   const ConvGeom& cg = p.A.g;
-  const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
+  const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && plain_ep && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
                     cg.stride == 1 && cg.pad == 1 && cg.H == 14 && cg.W == 14 && cg.nchw == 0 && cg.C % BK3 == 0 &&
                     p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
   if (halo) persist = true;
@@ -1351,7 +1371,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias,
-                 const BnFuseArgs* bn_fuse, int* bn_fused) {
+                 const BnFuseArgs* bn_fuse, int* bn_fused, int act) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
   Bf3Params p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -1359,7 +1379,7 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.A.kind = (d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) ? OPK_ROWK : OPK_IM2COL;
   p.A.ld = d.C; p.A.g = d.geom(); p.A.paired = 1;
   p.B.kind = OPK_ROWK; p.B.ld = d.K(); p.B.paired = 1;
-  p.ep = ep_store(y, d.CO, bias, ACT_NONE);
+  p.ep = ep_store(y, d.CO, bias, act);
   p.ep.stats = bn_partial;
   if (bn_fused) *bn_fused = 0;
   DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused));
@@ -1577,6 +1597,28 @@ static int gemm_bf16x3_any(int M, int N, int K, const uint16_t* a_hi, const uint
   if (paired) DIC_REQUIRE(K % 32 == 0, "gemm_bf16x3_paired: K %% 32");
   p.ep = ep_store(C, ldc, bias, ACT_NONE);
   return launch_bf3(p, (hipStream_t)stream, nullptr);
+}
+
+/* y = act(x W^T + b) (+= with accumulate) and NHWC convolution with bias / activation on the split-bf16 kernels, operands as
+ * paired planes (include/dic.h).  Used by the DPT front-end (dpt.py). */
+int dic_linear_bf16x3(int M, int N, int K, const uint16_t* const x_planes[3], const uint16_t* const w_planes[3], const float* bias,
+                      int act, int accumulate, float* C, long long ldc, void* stream) {
+  DIC_REQUIRE(x_planes && w_planes && C && M > 0 && N > 0 && K > 0 && K % 32 == 0, "linear_bf16x3: bad arguments (K %% 32)");
+  Bf3Params p{};
+  p.M = M; p.N = N; p.K = K;
+  for (int i = 0; i < 3; ++i) { p.A.p[i] = x_planes[i]; p.B.p[i] = w_planes[i]; }
+  p.A.ld = K; p.A.kind = OPK_ROWK; p.B.ld = K; p.B.kind = OPK_ROWK;
+  p.A.paired = p.B.paired = 1;
+  p.ep = ep_store(C, ldc, bias, act);
+  p.ep.accumulate = accumulate;
+  return launch_bf3(p, (hipStream_t)stream, nullptr);
+}
+int dic_conv2d_bf16x3(const uint16_t* const x_planes[3], int B, int H, int W, int Cin, const uint16_t* const w_planes[3],
+                      const float* bias, int CO, int KH, int KW, int stride, int pad, int act, float* y_nhwc, float* tail_ws,
+                      void* stream) {
+  DIC_REQUIRE(x_planes && w_planes && y_nhwc && Cin % 32 == 0, "conv2d_bf16x3: bad arguments (C %% 32)");
+  ConvDesc d{B, H, W, Cin, CO, KH, KW, stride, pad, 0};
+  return conv_fwd_bf3(x_planes, d, w_planes, y_nhwc, nullptr, nullptr, tail_ws, (hipStream_t)stream, bias, nullptr, nullptr, act);
 }
 
 int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,

@@ -29,7 +29,13 @@ def _same_pad(size: int, k: int, s: int) -> int:
 
 
 class DptRunner:
-    def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[DptConfig] = None):
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[DptConfig] = None, arith: str = "bf16x3"):
+        """arith: "bf16x3" (default) runs every convolution / linear layer whose contraction length is a multiple of 32 on the
+        split-bf16 kernels (fp32-accurate: three bf16 planes per operand, six MFMA products); "fp32" keeps them
+        on the exact-fp32 MFMA kernels (the 3-channel stem and the pointwise head always are)."""
+        if arith not in ("bf16x3", "fp32"):
+            raise _lib.DicError("DptRunner: arith must be 'bf16x3' or 'fp32'")
+        self.arith = arith
         self.lib = _lib.load()
         self.cfg = cfg or DptConfig()
         if self.cfg.embed % self.cfg.heads or self.cfg.embed // self.cfg.heads != 64:
@@ -64,19 +70,54 @@ class DptRunner:
             self.conv_w[key] = w
         self.pos_cache: Dict[tuple, torch.Tensor] = {}
         self.gn_ws: Optional[torch.Tensor] = None
+        self.w_planes: Dict[str, list] = {}                 # paired bf16x3 planes of [N][K] weight matrices (filters: OHWI rows)
+        self.x_planes: Optional[list] = None                # scratch planes of the current layer's input
+        self.tail_ws: Optional[torch.Tensor] = None
+
+    # ---- split-bf16 operands ---------------------------------------------------------------------
+    def _split(self, x2d: torch.Tensor, out: Optional[list] = None) -> list:
+        rows, k = x2d.shape
+        n = (rows + 1) // 2 * 2 * k
+        if out is None or out[0].numel() < n:
+            out = [torch.empty(n, dtype=torch.int16, device=self.dev) for _ in range(3)]
+        check(self.lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(rows), k, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()),
+              "dic_split_bf16x3_paired")
+        return out
+
+    def _weight_planes(self, key: str, w2d: torch.Tensor) -> list:
+        if key not in self.w_planes:
+            self.w_planes[key] = self._split(w2d.contiguous())
+        return self.w_planes[key]
+
+    def _input_planes(self, x2d: torch.Tensor) -> list:
+        self.x_planes = self._split(x2d, self.x_planes)      # one scratch set, grown to the largest layer input
+        return self.x_planes
+
+    @staticmethod
+    def _p3(planes: list):
+        return (C.c_void_p * 3)(*[t.data_ptr() for t in planes])
 
     # ---- operator wrappers ----------------------------------------------------------------------
     def _new(self, *shape) -> torch.Tensor:
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
 
     def conv(self, x: torch.Tensor, key: str, stride: int = 1, pad: int = 0, bias: bool = True, nchw: bool = False):
-        """x NHWC [B,H,W,C] (or NCHW when nchw) -> NHWC [B,OH,OW,CO] on the exact-fp32 MFMA implicit-GEMM kernel."""
+        """x NHWC [B,H,W,C] (or NCHW when nchw) -> NHWC [B,OH,OW,CO]: split-bf16 implicit GEMM (C % 32 == 0) or the exact-fp32
+        MFMA kernel (the 3-channel stem; arith "fp32")."""
         w = self.conv_w[key]
         co, ci, kh, kw = self.w[key + ".weight"].shape
         B, H, W = (x.shape[0], x.shape[2], x.shape[3]) if nchw else (x.shape[0], x.shape[1], x.shape[2])
         oh, ow = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         y = self._new(B, oh, ow, co)
         b = self.w[key + ".bias"] if bias else None
+        if self.arith == "bf16x3" and not nchw and ci % 32 == 0 and kh * kw <= 32:
+            if self.tail_ws is None:
+                self.tail_ws = torch.empty(256 * 64 * 64, dtype=torch.float32, device=self.dev)
+            xp = self._input_planes(x.reshape(-1, ci))
+            wp = self._weight_planes(key, w.reshape(co, -1))
+            check(self.lib.dic_conv2d_bf16x3(self._p3(xp), B, H, W, ci, self._p3(wp), ptr(b), co, kh, kw, stride, pad, ACT_NONE, ptr(y),
+                                             ptr(self.tail_ws), stream_ptr()), "dic_conv2d_bf16x3")
+            return y
         check(self.lib.dic_conv2d_fwd(ptr(x), B, H, W, ci, 1 if nchw else 0, ptr(w), ptr(b), co, kh, kw, stride, pad, ptr(y),
                                       C.c_void_p(0), C.c_void_p(0), 0, C.c_void_p(0), stream_ptr()), "dic_conv2d_fwd")
         return y
@@ -124,6 +165,12 @@ class DptRunner:
         m = x.numel() // k
         if out is None:
             out = self._new(*x.shape[:-1], n)
+        if self.arith == "bf16x3" and k % 32 == 0:
+            xp = self._input_planes(x.reshape(m, k))
+            wp = self._weight_planes(key, w.reshape(n, k))
+            check(self.lib.dic_linear_bf16x3(m, n, k, self._p3(xp), self._p3(wp), ptr(self.w[key + ".bias"]), act,
+                                             1 if accumulate else 0, ptr(out), C.c_longlong(n), stream_ptr()), "dic_linear_bf16x3")
+            return out
         check(self.lib.dic_gemm_f32(m, n, k, ptr(x), C.c_longlong(k), 0, ptr(w), C.c_longlong(k), 0, ptr(out), C.c_longlong(n),
                                     ptr(self.w[key + ".bias"]), act, 1 if accumulate else 0, 1, C.c_void_p(0), C.c_size_t(0), 0,
                                     stream_ptr()), "dic_gemm_f32")

@@ -261,6 +261,18 @@ int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi,
 int dic_gemm_bf16x3_paired(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                            const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, float* C, long long ldc,
                            const float* bias, void* stream);
+/* nn.Linear / nn.Conv2d of the DPT front-end on the split-bf16 kernels (fp32-accurate, ~2x the exact-fp32 MFMA rate; dpt.py):
+ *   C[M,N] (+)= act(x[M,K] W[N,K]^T + bias)      - the ViT blocks' qkv / proj / fc1 (GELU) / fc2 (vit.py:36-60 -> timm Block),
+ *                                                  the 1x1 projections of the reassemble stages (vit.py:345-477);
+ *   y[B,OH,OW,CO] = act(conv(x NHWC, w OHWI) + bias) - the residual conv units, fusion-block and head convolutions
+ *                                                  (blocks.py:231-341, dpt_depth.py:58-107), C % 32 == 0.
+ * Operands are paired planes (dic_split_bf16x3_paired of x viewed as [rows][K] resp. [B*H*W][C], of W as [N][K] resp.
+ * [CO][KH*KW*C]); act: 0 none, 1 ReLU, 2 sigmoid, 3 GELU; tail_ws (nullable): kGemmTailWsBytes of scratch as for dic_conv2d_fwd. */
+int dic_linear_bf16x3(int M, int N, int K, const uint16_t* const x_planes[3], const uint16_t* const w_planes[3], const float* bias,
+                      int act, int accumulate, float* C, long long ldc, void* stream);
+int dic_conv2d_bf16x3(const uint16_t* const x_planes[3], int B, int H, int W, int C, const uint16_t* const w_planes[3],
+                      const float* bias, int CO, int KH, int KW, int stride, int pad, int act, float* y_nhwc, float* tail_ws,
+                      void* stream);
 int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                     long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
                     float* C, long long ldc, const float* bias, void* stream);

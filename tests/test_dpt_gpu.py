@@ -75,6 +75,22 @@ def test_dpt_small_model_vs_oracle(lib, size, batch):
     assert e <= 2e-4
 
 
+def test_dpt_split_bf16_arithmetic_equals_exact_fp32(lib):
+    """DptRunner's default arithmetic (every convolution / linear layer with K % 32 == 0 on the bf16x3 kernels, the larger ones on
+    the persistent warp-specialised kernel with its bias / GELU / accumulate seam: dic_linear_bf16x3, dic_conv2d_bf16x3)
+    against the same runner on the exact-fp32 MFMA kernels and against the oracle: both within 2e-4 of scale of the oracle,
+    and within 1e-4 of each other, at a size where the persistent kernel is selected (160 x 160, batch 4)."""
+    cfg = syn.DptConfig(layers=(1, 1, 1), depth=2, hooks=(0, 1), pos_grid=4)
+    w = syn.dpt_weights(9, cfg)
+    wd = {k: v.to(DEV) for k, v in w.items()}
+    x = syn.dpt_images(4, seed=6, size=160)
+    ref = orc.dpt_forward(w, x, cfg)
+    out = {a: DptRunner(wd, cfg, arith=a).forward(x.to(DEV)) for a in ("bf16x3", "fp32")}
+    for a, got in out.items():
+        assert _err(got, ref) <= 2e-4, a
+    assert _err(out["bf16x3"], out["fp32"].cpu()) <= 1e-4
+
+
 def test_dpt_hybrid_full_model_384_vs_oracle(lib):
     """The real architecture (vitb_rn50_384: ResNetV2 (3,4,9) + 12 transformer blocks, hooks 0,1,8,11; 122 M parameters)
     at 384x384 through the drop-in module, followed by the training loop's epoch-0 post-processing
