@@ -56,7 +56,7 @@ int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* h
 int conv1_depth_fwd(const float* x, const ConvDesc& d, const float* w, const float* bias, float* y, float* bn_partial,
                     int* partial_rows, hipStream_t st);
 int conv1_depth_fwd_blocks(const ConvDesc& d);
-bool conv1_depth_supported(const ConvDesc& d);   // shape fits (rows <= 640 floats wide) and switched on (debug codes 131..134; off by default);
+bool conv1_depth_supported(const ConvDesc& d);   // shape fits (rows <= 640 floats wide) and not switched off (debug code 130);
                                                   // otherwise the caller uses the generic gather kernels
 size_t conv1_depth_wgrad_ws_floats(const ConvDesc& d);
 int conv1_depth_wgrad(const float* x, const ConvDesc& d, const float* dy, float* dw, float* dbias, float* ws, float* cs_ws,

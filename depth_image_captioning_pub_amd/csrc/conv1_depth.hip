@@ -11,14 +11,18 @@
 // Both are bound by the 128-channel fp32 activation stream (write of y / read of dy: 179 MB at batch 64).
 // Exact fp32 FMA arithmetic; summation order per output differs from the MFMA kernel only in the usual fp32 round-off.
 //
-// OFF BY DEFAULT since round 2 (debug codes 131..134 switch it on).  Alone on the chip both kernels are bit-reproducible,
-// but while the bf16x3 ResNet forward of the next batch runs on a second stream (engine.py, two forwards in flight) one
-// pixel in ~10^5 comes out with channels 48..63 (the x half of lanes 48..63, i.e. the last of the four 16-lane passes of
-// one packed FMA) off by up to 0.1 - in registers, the BatchNorm partial sums see it too.  Excluded so far: LDS written
-// by another workgroup (scripts/diag_lds_canary.py), the row ring (extra barriers, vmcnt(0) waits, static LDS: no change);
-// claiming the CU's whole LDS (one wave per SIMD) hides it, and so does any edit that shifts the instruction schedule
-// (scripts/diag_conv1_race.py).  Until that is understood the generic gather kernels carry layer 1: they were
-// bit-identical over every overlapped repetition, and the overlapped step costs the same with either (15.8 ms).
+// Reproducibility (round 2).  In their first form both kernels were bit-reproducible alone on the chip but not next to another
+// stream's LDS-heavy kernels (the gather bf16x3 convolutions of a concurrent ResNet forward, three workgroups per CU): one pixel
+// in ~10^5 came out with channels 48..63 - the x half of lanes 48..63, i.e. the last 16-lane beat of one operand - off by up
+// to 0.1, in registers (the BatchNorm partial sums saw it too); 59 of 59 repetitions differed (scripts/diag_conv1_race.py
+// with codes 70 75).  Excluded: LDS written by another workgroup (canary kernel), the row ring (extra barriers, vmcnt(0), static
+// LDS).  What the failing code did and the fixed code does not: it began a row's packed FMAs as soon as the compiler's COUNTED
+// s_waitcnt lgkmcnt(n > 0) said their own taps had arrived, while younger ds_read2_b32 of the same wave were still returning -
+// and the corrupted lanes are exactly those fed by the second dword of a ds_read2_b32 (op_sel picks the pair's upper register
+// for the low result).  Now every tap of a row is pinned in its register before the first FMA of that row (asm "+v" on each:
+// the compiler has to wait for all of them, lgkmcnt(0) in effect, and the late beat has tens of cycles to land): 0 of 59
+// repetitions differ under the same load, and tests/test_encoders_gpu.py::test_layer1_kernels_reproducible_next_to_lds_heavy_kernels
+// holds it.  Cost: a few microseconds per launch; still 0.03 + 0.08 ms per step better than the generic gather kernels.
 #include "conv.h"
 #include "nn_kernels.h"
 
@@ -114,6 +118,9 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
         float t[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) t[u] = p[kh * W + u];
+        // every tap of the row is in its register before the first FMA (see the note at the top of the file)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(t[u]));
 #pragma unroll
         for (int q = 0; q < PG; ++q)
 #pragma unroll
@@ -206,10 +213,14 @@ __global__ void __launch_bounds__(256, 3) conv1_wgrad_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < NT; ++u) t[u] = p[u];
 #pragma unroll
+      for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(t[u]));
+#pragma unroll
       for (int kh = 0; kh < KS; ++kh) {                 // row kh+1's taps are in flight during row kh's FMAs
         if (kh + 1 < KS) {
 #pragma unroll
           for (int u = 0; u < NT; ++u) tn[u] = p[(kh + 1) * W + u];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(tn[u]));      // (same: complete before the FMAs below)
         }
 #pragma unroll
         for (int q = 0; q < PG; ++q)
@@ -246,7 +257,7 @@ __global__ void __launch_bounds__(256, 3) conv1_wgrad_kernel(const float* __rest
 }
 
 static int g_c1_blocks = 512;     // persistent workgroups (<= 512 keeps the BatchNorm finalize a single launch)
-static int g_c1_on = 0;            // see the note at the top; debug codes 131..134 = on with 256..1024 workgroups, 130 = off
+static int g_c1_on = 1;            // debug codes 131..134 = on with 256..1024 workgroups (default 512), 130 = generic gather kernels instead
 void conv1_depth_debug_blocks(int n) { if (n <= 0) { g_c1_on = 0; return; } g_c1_on = 1; g_c1_blocks = n > 1024 ? 1024 : n; }
 bool conv1_depth_enabled() { return g_c1_on != 0; }
 

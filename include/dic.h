@@ -346,8 +346,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
  *   140 141      decoder forward loop: one launch pair per step (default) / one persistent launch for all steps
  *   142 143      persistent loop placement: a row group's 16 chunk workgroups on one XCD (default) / chunks 2x, 2x+1 on XCD x
- *   130..134     depth-encoder layer 1: generic MFMA gather path (default) / packed-FMA kernels with 256, 512, 768, 1024 workgroups
- *                (off by default: not bit-reproducible next to a concurrent bf16x3 forward, see csrc/conv1_depth.hip)
+ *   130..134     depth-encoder layer 1: generic MFMA gather path / packed-FMA kernels with 256, 512 (default), 768, 1024 workgroups
  * Unknown codes are rejected (DIC_ERR_ARG).
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,
  * 4 = deep-pipelined 128x128, 5 = persistent 128x128, 6 = LDS-halo 3x3. */

@@ -221,7 +221,7 @@ def test_overlapped_step_is_bit_reproducible_at_bench_shape(lib):
     weights while bf16x3 ResNet forwards of the next batches run on the two prefetch streams.  Loss, every gradient and the
     prefetched features must be bit-identical in every repetition: kernels sharing CUs with another stream's kernels is the
     normal operating condition of the pipelined step (the packed-FMA layer-1 kernels of round 1 failed exactly this, see
-    csrc/conv1_depth.hip; they are off by default)."""
+    csrc/conv1_depth.hip; fixed since, and guarded directly by test_layer1_kernels_reproducible_next_to_lds_heavy_kernels)."""
     B, V, T = 64, 10000, 20
     tr = CaptionTrainer(V, device=DEV, seed=123, resnet_layers=TINY, conv_mode="bf16x3")
     imgs = syn.rgb_images(B, seed=123).to(DEV); depth = syn.depth_maps(B, seed=123).to(DEV)
