@@ -216,13 +216,25 @@ def test_two_forwards_in_flight_equal_sequential_forwards(lib):
         tr.prefetch_features(batches[0]); tr.prefetch_features(batches[1]); tr.prefetch_features(batches[2])
 
 
-def test_overlapped_step_is_bit_reproducible_at_bench_shape(lib):
+@pytest.mark.parametrize("forward_kernels", ["policy", "gather"])
+def test_overlapped_step_is_bit_reproducible_at_bench_shape(lib, forward_kernels):
     """Bench shape (64 x 224 x 224, vocabulary 10000, T = 20): the gradient computation of a step is repeated on fixed
     weights while bf16x3 ResNet forwards of the next batches run on the two prefetch streams.  Loss, every gradient and the
     prefetched features must be bit-identical in every repetition: kernels sharing CUs with another stream's kernels is the
     normal operating condition of the pipelined step (the packed-FMA layer-1 kernels of round 1 failed exactly this, see
     csrc/conv1_depth.hip; fixed since, and guarded directly by test_layer1_kernels_reproducible_next_to_lds_heavy_kernels)."""
     B, V, T = 64, 10000, 20
+    if forward_kernels == "gather":      # the concurrent forwards on the round-1 gather kernels: three LDS-heavy workgroups per CU,
+        for code in (70, 75):            # the neighbours under which the layer-1 kernels used to fail
+            lib.dic_debug_force_staged_gemm(code)
+    try:
+        _overlapped_step_repetitions(B, V, T)
+    finally:
+        lib.dic_debug_force_staged_gemm(79)
+        lib.dic_debug_force_staged_gemm(78)
+
+
+def _overlapped_step_repetitions(B, V, T):
     tr = CaptionTrainer(V, device=DEV, seed=123, resnet_layers=TINY, conv_mode="bf16x3")
     imgs = syn.rgb_images(B, seed=123).to(DEV); depth = syn.depth_maps(B, seed=123).to(DEV)
     caps, lens = syn.captions_fixed(B, V, T, seed=123); caps = caps.to(DEV)
