@@ -8,6 +8,8 @@ namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_
                 void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p); }
 
 
+
+
 extern "C" {
 
 int dic_version(void) { return 100; }

@@ -12,17 +12,16 @@
 // Exact fp32 FMA arithmetic; summation order per output differs from the MFMA kernel only in the usual fp32 round-off.
 //
 // Reproducibility (round 2).  In their first form both kernels were bit-reproducible alone on the chip but not next to another
-// stream's LDS-heavy kernels (the gather bf16x3 convolutions of a concurrent ResNet forward, three workgroups per CU): one pixel
-// in ~10^5 came out with channels 48..63 - the x half of lanes 48..63, i.e. the last 16-lane beat of one operand - off by up
-// to 0.1, in registers (the BatchNorm partial sums saw it too); 59 of 59 repetitions differed (scripts/diag_conv1_race.py
-// with codes 70 75).  Excluded: LDS written by another workgroup (canary kernel), the row ring (extra barriers, vmcnt(0), static
-// LDS).  What the failing code did and the fixed code does not: it began a row's packed FMAs as soon as the compiler's COUNTED
-// s_waitcnt lgkmcnt(n > 0) said their own taps had arrived, while younger ds_read2_b32 of the same wave were still returning -
-// and the corrupted lanes are exactly those fed by the second dword of a ds_read2_b32 (op_sel picks the pair's upper register
-// for the low result).  Now every tap of a row is pinned in its register before the first FMA of that row (asm "+v" on each:
-// the compiler has to wait for all of them, lgkmcnt(0) in effect, and the late beat has tens of cycles to land): 0 of 59
-// repetitions differ under the same load, and tests/test_encoders_gpu.py::test_layer1_kernels_reproducible_next_to_lds_heavy_kernels
-// holds it.  Cost: a few microseconds per launch; still 0.03 + 0.08 ms per step better than the generic gather kernels.
+// stream's kernels (a concurrent bf16x3 ResNet forward): one pixel in ~10^5 came out with channels 48..63 - the x half of lanes
+// 48..63 - off by up to 0.1, in registers (the BatchNorm partial sums saw it too); 59 of 59 repetitions differed
+// (scripts/diag_conv1_race.py with codes 70 75).  Cause (scripts/diag_pk_fp32_opsel.py, a register-only reproducer): on gfx950
+// a packed fp32 instruction whose LOW result takes the HIGH half of src1 - `v_pk_fma_f32 ... op_sel:[0,1,0]`, which hipcc chose
+// for 69 of the 734 tap broadcasts because the tap sat in the upper register of a ds_read2_b32 pair - gives wrong results in
+// ~1e-5 of the lanes when the wave shares its SIMD with other kernels' waves; every other operand-select form is right.
+// Fix: each tap is pinned in a register of its own (asm "+v") before the row's FMAs, so a broadcast always reads the LOW
+// register of the pair the instruction names (op_sel_hi:[1,0,1], the safe form); build.py audits the device assembly of every
+// build for the bad forms, tests/test_encoders_gpu.py::test_layer1_kernels_reproducible_next_to_lds_heavy_kernels repeats the
+// failing scenario.  Cost: a few microseconds per launch; still 0.03 + 0.08 ms per step better than the generic gather kernels.
 #include "conv.h"
 #include "nn_kernels.h"
 
@@ -118,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) conv1_fwd_kernel(const float* __restri
         float t[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) t[u] = p[kh * W + u];
-        // every tap of the row is in its register before the first FMA (see the note at the top of the file)
+        // every tap in a register of its own: broadcasts then use the safe operand-select form (note at the top of the file)
 #pragma unroll
         for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(t[u]));
 #pragma unroll
@@ -220,7 +219,7 @@ __global__ void __launch_bounds__(256, 3) conv1_wgrad_kernel(const float* __rest
 #pragma unroll
           for (int u = 0; u < NT; ++u) tn[u] = p[(kh + 1) * W + u];
 #pragma unroll
-          for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(tn[u]));      // (same: complete before the FMAs below)
+          for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(tn[u]));      // (same)
         }
 #pragma unroll
         for (int q = 0; q < PG; ++q)

@@ -1,0 +1,36 @@
+"""Packed fp32 instructions with operand selects, alone and next to another stream's kernels (a bf16x3 ResNet forward on its gather
+kernels, debug codes 70 75): how many lanes get a wrong result?  Found through csrc/conv1_depth.hip: on gfx950 the forms whose LOW
+result takes the HIGH half of src1 (op_sel bit 1: v_pk_fma_f32 op_sel:[0,1,0], v_pk_add_f32 op_sel:[0,1]) are wrong in ~1e-5 of
+the lanes when the wave shares its SIMD with other kernels' waves - register operands only, no memory involved - and every
+other form (op_sel on src0 / src2, op_sel_hi, plain) and the scalar instructions are right.  Modes 0..4 are the LDS variants that
+were tried first (counted vs full lgkmcnt waits, ds_read2_b32 vs ds_read_b32).  build.py audits every build for the bad forms."""
+import os, sys, ctypes as C, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from depth_image_captioning_pub_amd import _lib, native, synthetic as syn
+from depth_image_captioning_pub_amd._lib import ptr
+lib = _lib.load(); dev = "cuda:0"
+for c in (70, 75): lib.dic_debug_force_staged_gemm(c)
+LAYERS = (1, 1, 1, 1)
+rn = native.ResNetRunner({k: v.to(dev) for k, v in syn.resnet152_weights(seed=125, layers=LAYERS).items()}, LAYERS, conv_mode="bf16x3")
+imgs = syn.rgb_images(64, seed=123).to(dev)
+hog = torch.cuda.Stream()
+with torch.cuda.stream(hog): rn.forward(imgs, True, compact=True)
+torch.cuda.synchronize()
+bad = torch.zeros(1, dtype=torch.int32, device=dev)
+for mode, name in ((0, "read2 + counted lgkmcnt(7..0) + pk_fma"), (1, "read2 + lgkmcnt(0) + pk_fma"), (2, "read2 + lgkmcnt(0) + 16 nops + pk_fma"),
+                   (3, "read2 + lgkmcnt(0) + v_add_f32"), (4, "16 x ds_read_b32 + lgkmcnt(0) + v_add_f32"),
+                   (5, "registers only: v_pk_fma_f32 op_sel:[0,1,0]"), (6, "registers only: plain v_pk_fma_f32"), (7, "registers only: v_fma_f32"),
+                   (8, "registers only: v_pk_fma_f32 op_sel_hi:[1,0,1]"), (9, "registers only: v_pk_mul_f32 op_sel:[1,0]"),
+                   (10, "registers only: v_pk_add_f32 op_sel:[0,1]"), (11, "registers only: v_pk_fma_f32 op_sel:[1,0,0]"),
+                   (12, "registers only: v_pk_fma_f32 op_sel:[0,0,1]")):
+    for with_hog in (False, True):
+        bad.zero_(); total = 0
+        for rep in range(30):
+            if with_hog:
+                with torch.cuda.stream(hog):
+                    for _ in range(6): rn.forward(imgs, True, compact=True)
+                time.sleep(0.004)
+            assert lib.dic_debug_lds_wait_probe(ptr(bad), 1024, 2000, mode, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+            torch.cuda.synchronize(); total += 1024 * 256 * 2000
+        print(f"{name:48s} {'next to LDS-heavy kernels' if with_hog else 'alone':26s}: {int(bad.item())} wrong lane-sums of {total:.2e}", flush=True)
