@@ -192,7 +192,7 @@ def parity_gate(first, dev: str, conv_mode: str, compact: bool):
 def bench_dpt(args, dev: str, world: int, rank: int):
     """`--dpt`: images/s of the frozen DPT-Hybrid depth front-end (config 5's extra stage, epoch 0 only): forward at 384x384 +
     per-image standardisation + resize to 224x224, inputs resident in HBM; every rank runs its own batch (no collective:
-    the estimator is frozen).  Reported beside: achieved exact-fp32 MFMA rate (algorithmic FLOPs / time), the CPU oracle on
+    the estimator is frozen).  Reported beside: achieved fp32-equivalent rate (algorithmic FLOPs / time) against the peak of the arithmetic in use, the CPU oracle on
     the host cores (2 images) and the max deviation of one predicted map from it (parity unpinned, see oracle/dpt_oracle.py)."""
     from depth_image_captioning_pub_amd import synthetic as syn
     from depth_image_captioning_pub_amd.Captioning_models.Depth_caption_model.DPT_model import DPT_Depthestimator
@@ -220,6 +220,8 @@ def bench_dpt(args, dev: str, world: int, rank: int):
     if rank == 0:
         flops = dpt._runner.flops_per_image(384) * B * args.steps
         ach = flops / elapsed / 1e12
+        arith = dpt._runner.arith
+        peak = PEAK_BF16X3_TFLOPS if arith == "bf16x3" else PEAK_F32_MFMA_TFLOPS
         res = {"metric": "images/sec (DPT-Hybrid depth front-end forward, 384x384 -> 224x224 depth maps)",
                "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -227,9 +229,10 @@ def bench_dpt(args, dev: str, world: int, rank: int):
                "config": {"workload": f"frozen DPT-Hybrid (vitb_rn50_384, 122 M parameters, random init) forward at 384x384, "
                                       f"batch {B}/GPU, + standardize_depth_map + resize to 224x224 (BASELINE config 5 front-end)",
                           "batch_per_gpu": B, "parallelism": f"dp{world} (replicas, no collective: frozen)"},
-               "roofline": {"bound": "mfma", "kernel": "whole forward (exact-fp32 MFMA convolutions / linear layers)",
-                            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+               "roofline": {"bound": "mfma", "kernel": f"whole forward (convolutions / linear layers in {arith} arithmetic)",
+                            "achieved": round(ach, 2), "peak": peak,
+                            "unit": "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)" if arith == "bf16x3" else "TFLOP/s",
+                            "frac": round(ach / peak, 4), "traffic": None,
                             "gflop_per_image": round(dpt._runner.flops_per_image(384) / 1e9, 1)}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import dpt_oracle
