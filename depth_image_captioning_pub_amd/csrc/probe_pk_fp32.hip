@@ -79,6 +79,24 @@ __global__ void __launch_bounds__(256) lds_wait_probe_kernel(unsigned* bad, int 
         } else if (mode == 11) {// v_pk_fma_f32 op_sel:[1,0,0]
           asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(d) : "v"(pa), "v"(pb), "v"(pc));
           want_x = a1 * 3.f + 7.f; want_y = a1 * 5.f + 11.f;
+        } else if (mode == 13) {// op_sel_hi:[0,1,1]: high result takes src0's LOW half
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(pa), "v"(pb), "v"(pc));
+          want_x = a0 * 3.f + 7.f; want_y = a0 * 5.f + 11.f;
+        } else if (mode == 14) {// op_sel_hi:[1,1,0]: high result takes src2's LOW half
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(d) : "v"(pb), "v"(pc), "v"(pa));
+          want_x = 3.f * 7.f + a0; want_y = 5.f * 11.f + a0;
+        } else if (mode == 15) {// op_sel_hi:[1,0,0]
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pb), "v"(pa), "v"(pc));
+          want_x = 3.f * a0 + 7.f; want_y = 5.f * a0 + 7.f;
+        } else if (mode == 16) {// v_pk_mul_f32 op_sel_hi:[0,1]
+          asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(pa), "v"(pb));
+          want_x = a0 * 3.f; want_y = a0 * 5.f;
+        } else if (mode == 17) {// v_pk_mul_f32 op_sel_hi:[1,0]
+          asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(pb), "v"(pa));
+          want_x = 3.f * a0; want_y = 5.f * a0;
+        } else if (mode == 18) {// op_sel:[0,1,0] together with op_sel_hi:[1,0,1] (src1 swapped: low result from hi, high from lo)
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(pb), "v"(pa), "v"(pc));
+          want_x = 3.f * a1 + 7.f; want_y = 5.f * a0 + 11.f;
         } else {                // mode 12: v_pk_fma_f32 op_sel:[0,0,1]
           asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(d) : "v"(pb), "v"(pc), "v"(pa));
           want_x = 3.f * 7.f + a1; want_y = 5.f * 11.f + a1;

@@ -23,7 +23,10 @@ for mode, name in ((0, "read2 + counted lgkmcnt(7..0) + pk_fma"), (1, "read2 + l
                    (5, "registers only: v_pk_fma_f32 op_sel:[0,1,0]"), (6, "registers only: plain v_pk_fma_f32"), (7, "registers only: v_fma_f32"),
                    (8, "registers only: v_pk_fma_f32 op_sel_hi:[1,0,1]"), (9, "registers only: v_pk_mul_f32 op_sel:[1,0]"),
                    (10, "registers only: v_pk_add_f32 op_sel:[0,1]"), (11, "registers only: v_pk_fma_f32 op_sel:[1,0,0]"),
-                   (12, "registers only: v_pk_fma_f32 op_sel:[0,0,1]")):
+                   (12, "registers only: v_pk_fma_f32 op_sel:[0,0,1]"), (13, "registers only: v_pk_fma_f32 op_sel_hi:[0,1,1]"),
+                   (14, "registers only: v_pk_fma_f32 op_sel_hi:[1,1,0]"), (15, "registers only: v_pk_fma_f32 op_sel_hi:[1,0,0]"),
+                   (16, "registers only: v_pk_mul_f32 op_sel_hi:[0,1]"), (17, "registers only: v_pk_mul_f32 op_sel_hi:[1,0]"),
+                   (18, "registers only: v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]")):
     for with_hog in (False, True):
         bad.zero_(); total = 0
         for rep in range(30):
