@@ -738,6 +738,12 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
         if (!plain) {      // bias / activation / accumulate (finalize_store's order): the stored value replaces the accumulator
           const int n = n0 + jj * 32;
           const float bcol = (p.ep.bias && n < p.N) ? p.ep.bias[n] : 0.f;
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {        // C += result: all 16 old values in flight before the first store
+            const bool in = m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n < p.N;
+            old[r] = (p.ep.accumulate && in) ? col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] : 0.f;
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[i][jj][r] + bcol;
@@ -745,13 +751,8 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
             else if (p.ep.act == ACT_SIGMOID) v = sigmoidf_(v);
             else if (p.ep.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
             const bool in = m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n < p.N;
-            float* dst = col + (long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc;
-            if (in) {
-              if (p.ep.accumulate) v += *dst;
-              *dst = v;
-            } else {
-              v = 0.f;       // outside the matrix: nothing stored, nothing in the statistics
-            }
+            v = in ? v + old[r] : 0.f;          // outside the matrix: nothing stored, nothing in the statistics
+            if (in) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = v;
             acc[i][jj][r] = v;
           }
         } else if (full) {
