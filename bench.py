@@ -19,7 +19,8 @@ processes --batch images per step (default 64 = BASELINE.json configs[1]); value
 
 The JSON line also carries
   roofline     - the contraction kernel instantiation with the largest total time (per-launch HIP events on the
-                 launch stream, algorithmic FLOPs / measured time, peak = 157.3 TFLOP/s exact-fp32 MFMA),
+                 launch stream, algorithmic FLOPs / measured time; peak = 2.5 PFLOP/s dense bf16 MFMA / 6 products per
+                 fp32-equivalent multiply-add = 416.7 TFLOP/s for the split-bf16 kernels, 157.3 TFLOP/s for the exact-fp32 MFMA kernels),
   cpu_baseline - the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample,
   parity       - same-run parity gate: the first oracle step of the cpu_baseline leg (initial weights,
                  batch --cpu-batch, explicit dropout mask) against one GPU step on the same tensors: |loss difference|
@@ -71,10 +72,12 @@ def profile_step(trainer, args_step):
         k = keys[i]
         if k >= 2000:                                   # split-bf16 convolution kernel (gemm_bf3.hip)
             a, tcode = (k - 2000) // 10, (k - 2000) % 10
-            if tcode >= 4:                                  # 128x128: deep-pipelined / persistent (warp-specialised) / LDS-halo 3x3
+            if tcode >= 4:                                  # 128x128: persistent warp-specialised / LDS-halo 3x3 (4, 7, 8: parked forms, experiments library only)
                 name, rname = {4: (f"gemm_bf3_pipe_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_pipe_kernel<{a}, "),
                                5: (f"gemm_bf3_persist_ws_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws_kernel<{a}"),
-                               6: ("conv3x3_bf3_halo_kernel", "conv3x3_bf3_halo_kernel<0>")}[tcode]
+                               6: ("conv3x3_bf3_halo_kernel", "conv3x3_bf3_halo_kernel<0>"),
+                               7: (f"gemm_bf3_persist_ws256_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws256_kernel<{a}"),
+                               8: (f"gemm_bf3_persist_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_kernel<{a}")}[tcode]
                 rows.append({"kernel": name, "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i],
                              "peak": PEAK_BF16X3_TFLOPS})
                 continue
@@ -259,8 +262,10 @@ def launch_ranks(n: int) -> int:
     `python -m torch.distributed.run` job BEFORE this process touches a GPU, relay their output, return the exit code."""
     import socket
     import subprocess
-    if not os.environ.get("DIC_SHARE_GPU") and torch.cuda.device_count() < n:     # (device_count does not initialise HIP)
-        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+    from depth_image_captioning_pub_amd.hostinfo import visible_gpus
+    seen = visible_gpus()       # environment / sysfs only: this parent never calls into the HIP runtime
+    if not os.environ.get("DIC_SHARE_GPU") and seen is not None and seen < n:
+        print(f"bench.py: --gpus {n} but only {seen} GPU(s) are visible", file=sys.stderr)
         return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -339,7 +344,7 @@ def main():
 
     if os.environ.get("DIC_DEBUG_SWITCHES"):          # development only: comma-separated dic_debug_force_staged_gemm codes
         for code in os.environ["DIC_DEBUG_SWITCHES"].split(","):
-            _lib.load().dic_debug_force_staged_gemm(int(code))
+            _lib.check(_lib.load().dic_debug_force_staged_gemm(int(code)), f"debug switch {code}")
     if args.dpt:
         return bench_dpt(args, dev, world, rank)
     B = args.batch

@@ -9,6 +9,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdic_hip.so")
+LIB_EXPERIMENTS_PATH = os.path.join(HERE, "libdic_experiments.so")      # parked kernels + ablation switches: scripts/ only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "dic.h")
 
 _lib: Optional[C.CDLL] = None
@@ -26,10 +27,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DicError(f"{LIB_PATH} is missing: build it with `python -m depth_image_captioning_pub_amd.build` "
-                       "(hipcc, gfx950). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    path = LIB_PATH
+    if os.environ.get("DIC_LIB") == "experiments":      # development scripts (scripts/): same sources + -DDIC_EXPERIMENTS
+        path = LIB_EXPERIMENTS_PATH
+    if not os.path.exists(path):
+        raise DicError(f"{path} is missing: build it with `python -m depth_image_captioning_pub_amd.build"
+                       f"{' --experiments' if path != LIB_PATH else ''}` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
     lib.dic_version.restype = C.c_int
     lib.dic_last_error.restype = C.c_char_p
     _lib = lib

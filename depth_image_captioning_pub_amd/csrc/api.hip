@@ -4,11 +4,10 @@
 
 using namespace dic;
 
-namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); void decoder_debug_persistent(int on);
-                void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p); }
-
-
-
+namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); }
+#ifdef DIC_EXPERIMENTS
+namespace dic { void decoder_debug_persistent(int on); void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p); }
+#endif
 
 extern "C" {
 
@@ -40,18 +39,24 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
   return conv_fwd(x, d, w_ohwi, bias, y_nhwc, bn_partial, mtiles_out, (hipStream_t)stream, force_tile, tail_ws);
 }
 
+/* Kernel-selection switches (include/dic.h).  The product library accepts the codes its own tests use to put two product
+ * kernels side by side; every other code (ablations, parked kernels) exists only in the experiments build. */
 int dic_debug_force_staged_gemm(int on) {
-  if (on == 140 || on == 141) { dic::decoder_debug_persistent(on - 140); return 0; }
-  if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement   // decoder forward: per-step launches / persistent loop
+  if (gemm_bf3_force_tile(on) == 0) return 0;
+#ifdef DIC_EXPERIMENTS
+  if (on == 140 || on == 141) { dic::decoder_debug_persistent(on - 140); return 0; }          // decoder forward: per-step launches / persistent loop
+  if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement
   if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
-  if (on == 11 || on == 21 || on == 22 || on == 23 || on == 24 || on == 26 || on == 20 || on == 31 || on == 32 || on == 42 || on == 43 || (on >= 50 && on <= 53) || (on >= 60 && on <= 63) || (on >= 70 && on <= 89)) gemm_bf3_force_tile(on == 20 ? 0 : on);
-  else if (on >= 0 && on <= 13) gemm_force_v1(on);
-  else DIC_REQUIRE(false, "debug switch: unknown code");
+  if (on >= 0 && on <= 13) { gemm_force_v1(on); return 0; }
+#endif
+  DIC_REQUIRE(false, "debug switch: unknown code %d", on);
   return 0;
 }
+#ifdef DIC_EXPERIMENTS
 /* development aid (not in dic.h): device buffer [T][8] receiving phase time stamps of the persistent decoder loop */
 int dic_debug_decoder_stamps(unsigned long long* dev_buf) { dic::decoder_persist_debug_buffer(dev_buf); return 0; }
+#endif
 /* development aid (not in dic.h): depth-encoder layer-1 kernels alone (csrc/conv1_depth.hip); y [B,OH,OW,128]; ws >= 1024 * 6400 floats */
 int dic_debug_conv1_wgrad(const float* x, int B, int H, int W, const float* dy, float* dw, float* dbias, float* ws, float* cs_ws,
                           void* stream) {

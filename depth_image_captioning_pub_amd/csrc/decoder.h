@@ -26,7 +26,7 @@ struct DecoderWs {
   float *alpha_c, *dalpha_c;     // compact (49-cell) mode: group softmax [B,T,49] and its incoming gradient
   float* dXe;                    // [B,T,E] gradient of the embedded input rows (reduced per token after BPTT)
   int* dlen;
-  // persistent forward loop (decoder_persist.hip)
+  // persistent forward loop (experiments/decoder_persist.hip; carved in the experiments build only)
   float* Gemb;                   // [B*T, 4H] embedding part of the gate pre-activations + bias
   float* pslab;                  // [2][16][16][4][4H] partial gate pre-activations exchanged per step
   unsigned int* psync;           // [16] arrival counters + [1] status word
@@ -39,7 +39,7 @@ struct DecoderWs {
 
 DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, bool* overflow);
 
-// One launch for all T forward steps (soft attention, B <= 64); see decoder_persist.hip.  Expects F, P, h0/c0 (slot 0 of
+// Experiments build only (-DDIC_EXPERIMENTS): one launch for all T forward steps (soft attention, B <= 64); see experiments/decoder_persist.hip.  Expects F, P, h0/c0 (slot 0 of
 // Hall/Call), the embedding columns of Xall, WhT / WbT / WcatT, Gemb and the device copy of the lengths in the workspace.
 bool decoder_persist_eligible(int B, int T, int mode);
 int decoder_fwd_persistent(const DecoderWs& ws, const dic_decoder_weights* w, int B, int T, int cells, const float* drop_mult,

@@ -67,10 +67,12 @@ DecoderWs decoder_carve(void* ws, size_t ws_bytes, int B, int T, int V, int N, b
   w.dalpha_c = c.take<float>(BT * kLc);
   w.dXe = c.take<float>(BT * kE);
   w.dlen = c.take<int>((size_t)B);
+#ifdef DIC_EXPERIMENTS
   w.Gemb = c.take<float>(BT * kG);
   w.pslab = c.take<float>((size_t)2 * 16 * 16 * 4 * kG);
   w.psync = c.take<unsigned int>(32);
   w.poff = c.take<int>((size_t)T + 2);
+#endif
   w.logits_step = c.take<float>((size_t)B * V);
   w.ids = c.take<long long>((size_t)B);
   w.bytes = c.off;
@@ -1030,10 +1032,13 @@ __global__ void __launch_bounds__(256) fold_dalphas_kernel(const float* __restri
   dc[i] = 0.25f * ((r[0] + r[1]) + (r[14] + r[15]));
 }
 
-// The persistent forward loop is an opt-in experiment (switch 141): correct (tests/test_decoder_gpu.py runs it against the
-// oracle) but at batch 64 it takes 20 us per step against 21.7 us for the two launches it replaces - see DESIGN.md 5.3.
+// The persistent forward loop (csrc/experiments/decoder_persist.hip, switch 141) is a parked experiment: correct, but at
+// batch 64 it takes 20 us per step against 21.7 us for the two launches it replaces.  It exists only in the
+// experiments build; the product library always runs the per-step launches.
+#ifdef DIC_EXPERIMENTS
 static int g_persistent = 0;
 void decoder_debug_persistent(int on) { g_persistent = on; }
+#endif
 
 // runs STMT with a compile-time cell count L_ (196 = reference layout, 49 = compact)
 #define DIC_CELLS_SWITCH(CELLS, STMT)   \
@@ -1133,12 +1138,16 @@ static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* fe
                      d_len, T, V, ws.Xall);
   DIC_LAUNCH_CHECK();
 
+#ifdef DIC_EXPERIMENTS
   const bool persistent = g_persistent && decoder_persist_eligible(B, T, mode);
   if (persistent) {
     // embedding part of every step's gate pre-activations (time-invariant under teacher forcing) + (b_ih + b_hh)
     DIC_TRY(gemm(B * T, kG, kE, op_rowk(ws.Xall, kXK), op_rowk(ws.Wcat, kXK), ep_store(ws.Gemb, kG, ws.bcat), st));
     DIC_TRY(decoder_fwd_persistent(ws, w, B, T, cells, drop_mult, alphas, pl.off.data(), st));
   }
+#else
+  constexpr bool persistent = false;
+#endif
   for (int t = 0; t < T && !persistent; ++t) {
     const int nb = pl.bs[t];
     // steps t >= 1 carry the LSTM cell of step t-1 in their prologue (FusedLstm); rows that ended at t-1 are

@@ -89,7 +89,7 @@ GemmOperand op_gather(const float* x, const ConvGeom& g);
 GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
 GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
 void gemm_force_v1(int on);
-void gemm_bf3_force_tile(int code);
+int gemm_bf3_force_tile(int code);      // 0 = accepted, -1 = unknown code in this build
 int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st);
 
 // Train-mode BatchNorm finalize fused into the tail fix-up launch (saves one dependent dispatch per tail-split

@@ -347,272 +347,9 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 }
 
 
-// Deep-pipelined variant (round 2): 128x128 workgroup tile, 4 waves of 64x64 (12 fragment reads per 24 MFMAs instead of 9
-// per 12 for the 128x64 tile: LDS bytes per MFMA cycle 1.12 -> 0.75), ONE workgroup = one wave per SIMD per CU with the
-// whole register file, so latency is hidden inside the wave instead of by co-resident workgroups:
-//   * fragment registers are double-buffered by k-step: while the 24 MFMAs of k-step s run, the 12 reads of the next
-//     k-step (of the next K tile, for s = 1) are in flight;
-//   * one raw barrier per K tile, in the middle of it: by then a wave has all fragments of the tile in registers
-//     (lgkmcnt(0)) and its share of the next tile's DMA - issued a whole tile earlier - has long landed (vmcnt(0)), so
-//     neither wait stalls in steady state; after the barrier the stage just read is re-filled with tile it+2;
-//   * DMA issue and fragment reads are placed textually inside the MFMA runs (MFMA issue leaves 7 of 8 slots free).
-// Same per-element summation order as gemm_bf3_kernel (K ascending, small products first): bit-identical results.
-template <int AK, int NST, int ABL = 0>      // ABL (measurement only): 1 = no DMA inside the loop, 2 = also no barrier, 3 = also no fragment reads
-__global__ void __launch_bounds__(256) gemm_bf3_pipe_kernel(const Bf3Params p) {
-  constexpr int BM = 128, BN = 128;
-  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
-  __shared__ __align__(1024) unsigned short smem[NST * STAGE];     // 48 KB per stage
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nkt = (p.K + BK3 - 1) / BK3;
-  const int t = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
-
-  Bf3Loader<AK, BM> la;
-  Bf3Loader<OPK_ROWK, BN> lbld;
-  la.init(p.A, tm * BM, p.M, p.K);
-  lbld.init(p.B, tn * BN, p.N, p.K);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#pragma unroll
-  for (int s0 = 0; s0 < NST; ++s0)
-    if (s0 < nkt) { la.issue(s0 * BK3, smem + s0 * STAGE); lbld.issue(s0 * BK3, smem + s0 * STAGE + AOPER); }
-
-  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
-  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
-  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
-  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
-
-  u32x4 fa[2][2][3], fb[2][2][3];          // [k-step buffer][tile][plane]
-#define DIC_PIPE_READ_A(KS_, SB_, I_)                                                                                \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
-      bf3_lds_read(fa[KS_][I_][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)((I_) * 32 * 64) + pos[KS_]);
-#define DIC_PIPE_READ_B(KS_, SB_, J_)                                                                                \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
-      bf3_lds_read(fb[KS_][J_][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)((J_) * 32 * 64) + pos[KS_]);
-#define DIC_PIPE_PIN(KS_)                                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
-    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
-#define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
-                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
-
-  // prologue: tile 0 landed (tile 1's 12 DMA instructions may stay in flight), k-step 0 fragments on their way
-  if (nkt >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (NST - 1)) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
-
-  for (int it = 0; it < nkt; ++it) {
-    const int st = it % NST, stn = (it + 1) % NST;
-    const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
-    unsigned short* cur = smem + st * STAGE;
-    // ---- k-step 0: its fragments were requested one k-step ago; request k-step 1 of this tile
-    if constexpr (ABL < 3) { DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1) }
-    if constexpr (ABL < 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-    DIC_PIPE_PIN(0)
-    __builtin_amdgcn_sched_barrier(0);
-    // small terms first: al*bh, ah*bl, am*bm, am*bh, ah*bm, ah*bh   (plane 0 = hi, 1 = mid, 2 = lo)
-    DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- middle of the tile: every read of this stage has returned, the next tile has landed
-    // (tiles it+2 .. it+NST-1 may stay in flight: 12 DMA instructions each, retired in order)
-    if (NST == 2 || it + NST - 1 >= nkt) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(12 * (NST - 2)) : "memory");
-    DIC_PIPE_PIN(1)
-    if constexpr (ABL < 2) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- k-step 1, with the refill of this stage (tile it+2) and the next tile's k-step-0 reads in its shadow
-    DIC_PIPE_MFMA(1, 2, 0)
-    if (ABL < 3 && it + 1 < nkt) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
-    DIC_PIPE_MFMA(1, 0, 2)
-    if (ABL == 0 && it + NST < nkt) la.issue((it + NST) * BK3, cur);
-    DIC_PIPE_MFMA(1, 1, 1)
-    if (ABL == 0 && it + NST < nkt) lbld.issue((it + NST) * BK3, cur + AOPER);
-    DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef DIC_PIPE_READ_A
-#undef DIC_PIPE_READ_B
-#undef DIC_PIPE_PIN
-#undef DIC_PIPE_MFMA
-  __syncthreads();
-  gemm_epilogue<BM, BN>(p, acc, tm, tn, 0, reinterpret_cast<float*>(smem));
-}
-
-
-// Persistent form of the deep-pipelined kernel: one workgroup per CU walks the output tiles  xcd_remap(blockIdx.x + j*grid)
-// and treats their K tiles as ONE stream of slots through a 3-stage ring (144 KB), so that what a fresh workgroup pays per
-// output tile - launch, loader set-up, the first DMA round trip, the drain of its stores (4.8 us per 128x128 tile against
-// 0.7 us per K tile: 40 % of a K = 256 tile) - disappears into the stream.  What it cannot change is the steady state, and
-// that is set by operand intake, not by the matrix cores: 48 KB per K tile arrive at ~68 GB/s per CU (two slots in flight
-// over ~1.4 us of loaded L2/HBM latency; the same figure the hardware guide measures for an LDS-DMA ring), i.e. 0.72 us per
-// K tile against 0.64 us of MFMA work at full rate - every tile shape of this file ends at 0.33-0.46 of the bf16 peak for
-// that reason, and only fewer operand bytes per FLOP (larger tiles, operand reuse in LDS) can move it.
-//   * the prefetch position (tile pj, K tile pkt) runs three slots ahead of the compute position and crosses tile seams;
-//     the loader state belongs to the prefetch side only and is re-derived in the MFMA shadow when it crosses;
-//   * at a seam the 64 stores of the tile go out straight from the accumulators; they sit in the vector-memory queue
-//     behind the DMA of the next two slots that is already in flight, and the counted wait of the two slots after a seam
-//     is vmcnt(63): at least 63 younger operations (64 stores + 12 DMA instructions) exist in issue order, so "at most 63
-//     outstanding" already guarantees the slot that is needed without waiting for any store's acknowledgement;
-//     masked edge tiles (whose stores may be skipped) fall back to the plain count, which only waits for more;
-//   * BatchNorm partial sums are written per 64-row wave tile ([2*mtiles][2][N]: no LDS exchange, no extra barrier).
-// Requires: plain store epilogue without bias (the ResNet convolutions), K >= 64.  Bit-identical to gemm_bf3_kernel.
-template <int AK>
-__global__ void __launch_bounds__(256) gemm_bf3_persist_kernel(const Bf3Params p) {
-  constexpr int BM = 128, BN = 128, NST = 3;
-  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
-  __shared__ __align__(1024) unsigned short smem[NST * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nkt = (p.K + BK3 - 1) / BK3;
-  const int T = p.mtiles * p.ntiles, G = gridDim.x;
-  const int ntl = (T - (int)blockIdx.x + G - 1) / G;            // tiles of this workgroup
-  const int total = ntl * nkt;                                    // slots
-
-  Bf3Loader<AK, BM> la;
-  Bf3Loader<OPK_ROWK, BN> lbld;
-  int pj = 0, pkt = 0;                                            // prefetch position
-  {
-    const int t = xcd_remap(blockIdx.x, T);
-    la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
-    lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
-  }
-  auto prefetch = [&](unsigned short* stage) {                   // issue the slot at the prefetch position, advance it
-    la.issue(pkt * BK3, stage);
-    lbld.issue(pkt * BK3, stage + AOPER);
-    if (++pkt == nkt) {
-      pkt = 0; ++pj;
-      if (pj < ntl) {
-        const int t = xcd_remap(blockIdx.x + pj * G, T);
-        la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
-        lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
-      }
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#pragma unroll
-  for (int s0 = 0; s0 < NST; ++s0)
-    if (s0 < total) prefetch(smem + s0 * STAGE);
-
-  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
-  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
-  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
-  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
-
-  u32x4 fa[2][2][3], fb[2][2][3];
-#define DIC_PIPE_READ_A(KS_, SB_, I_)                                                                                \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
-      bf3_lds_read(fa[KS_][I_][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)((I_) * 32 * 64) + pos[KS_]);
-#define DIC_PIPE_READ_B(KS_, SB_, J_)                                                                                \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
-      bf3_lds_read(fb[KS_][J_][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)((J_) * 32 * 64) + pos[KS_]);
-#define DIC_PIPE_PIN(KS_)                                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
-    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
-#define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
-                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
-
-  if (total > NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (NST - 1)) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
-
-  int g = 0, st = 0;                               // slot, its ring stage
-  int since_seam = 2;                              // slots since a FULL tile's 64 + 4 stores were issued (>= 2: none in range)
-  for (int j = 0; j < ntl; ++j) {
-    for (int kt = 0; kt < nkt; ++kt, ++g) {
-      const int stn = st == NST - 1 ? 0 : st + 1;
-      const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
-      unsigned short* cur = smem + st * STAGE;
-      DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
-      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-      DIC_PIPE_PIN(0)
-      __builtin_amdgcn_sched_barrier(0);
-      DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      // Slot g+1 (issued two slots ago) must have landed.  Younger than it, in issue order: slot g+2's 12 DMA instructions
-      // and, if a seam lies less than two slots back, that tile's 64 stores (+ statistics): >= 63 operations, so "at most
-      // 63 outstanding" already implies slot g+1 - without waiting for the stores' acknowledgements.
-      if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else if (since_seam < 2) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-      DIC_PIPE_PIN(1)
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      DIC_PIPE_MFMA(1, 2, 0)
-      if (g + 1 < total) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
-      DIC_PIPE_MFMA(1, 0, 2)
-      if (g + NST < total) prefetch(cur);
-      DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      st = stn;
-      ++since_seam;
-    }
-    // ---- seam: store the tile (the next tile's first fragments and two slots of DMA are already under way)
-    const int t = xcd_remap(blockIdx.x + j * G, T);
-    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
-    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
-    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
-        if (full) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
-              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
-          cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
-          acc[i][jj][r] = 0.f;
-        }
-      }
-    if (p.ep.stats) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
-        const int n = n0 + jj * 32;
-        if (lane < 32 && n < p.N) {
-          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 0) * p.N + n] = a;
-          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 1) * p.N + n] = b;
-        }
-      }
-    }
-    since_seam = full ? 0 : 2;
-  }
-#undef DIC_PIPE_READ_A
-#undef DIC_PIPE_READ_B
-#undef DIC_PIPE_PIN
-#undef DIC_PIPE_MFMA
-}
+#ifdef DIC_EXPERIMENTS
+#include "experiments/gemm_bf3_parked.inc"      // parked kernels (pipe / persistent without producer waves / 256x128): experiments build only
+#endif
 
 
 // Warp-specialised form of gemm_bf3_persist_kernel: waves 0..3 only compute (fragment reads, MFMAs, stores), waves 4..7 only
@@ -786,157 +523,6 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 #undef DIC_PIPE_READ_B
 #undef DIC_PIPE_PIN
 #undef DIC_PIPE_MFMA
-}
-
-// 256x128 form of the warp-specialised persistent kernel (MEASURED, NOT USED BY DEFAULT: 203 -> 216 us on 50176x256x1024,
-// 689 -> 740 us on 4096^3), for grids deep enough to fill the CUs with half as many tiles: eight computing waves (4 x 2, 64x64 each) + four producer waves = three waves per SIMD, 168 registers each.
-// Operand bytes per MFMA drop by a quarter (72 KB per K tile for twice the MFMAs), which is what the 128x128 form still waits
-// for (scripts/bench_bf3_ws_ablate.py: 3100-3900 cycles per K tile against 2400-2600 without any DMA).  Two ring stages of
-// 72 KB; B fragments are single-buffered (the second computing wave of the SIMD covers their latency), A fragments stay
-// double-buffered by k-step.  BatchNorm partials per 64-row wave tile: [4*mtiles][2][N].  Bit-identical to gemm_bf3_kernel.
-template <int AK>
-__global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Params p) {
-  constexpr int BM = 256, BN = 128, NST = 2;
-  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
-  constexpr int NDMA = 3 * (BM / 64) + 3 * (BN / 64);             // 18 DMA instructions per producer wave and K tile
-  __shared__ __align__(1024) unsigned short smem[NST * STAGE];     // 144 KB
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nkt = (p.K + BK3 - 1) / BK3;
-  const int T = p.mtiles * p.ntiles, G = gridDim.x;
-  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
-  const int total = ntl * nkt;
-
-  if (wave >= 8) {
-    // ---------------- producer waves (8..11 -> row groups 0..3 of the loaders)
-    Bf3Loader<AK, BM> la;
-    Bf3Loader<OPK_ROWK, BN> lbld;
-    int pj = 0, pkt = 0;
-    {
-      const int t = xcd_remap(blockIdx.x, T);
-      la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
-      lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
-    }
-    auto prefetch = [&](unsigned short* stage) {
-      la.issue(pkt * BK3, stage);
-      lbld.issue(pkt * BK3, stage + AOPER);
-      if (++pkt == nkt) {
-        pkt = 0; ++pj;
-        if (pj < ntl) {
-          const int t = xcd_remap(blockIdx.x + pj * G, T);
-          la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
-          lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
-        }
-      }
-    };
-    prefetch(smem);
-    if (total > 1) { prefetch(smem + STAGE); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
-    for (int g = 0; g < total; ++g) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // slot g+1 (issued a whole K tile ago) has landed
-      __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage g & 1
-      if (g + NST < total) prefetch(smem + (g & 1) * STAGE);
-    }
-    return;
-  }
-
-  // ---------------- consumer waves
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
-  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
-  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
-  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
-  u32x4 fa[2][2][3], fb[2][3];                     // A: [k-step buffer][tile][plane];  B: [tile][plane]
-#define DIC_W_READ_A(KS_, SB_)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
-      bf3_lds_read(fa[KS_][i][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)(i * 32 * 64) + pos[KS_]);
-#define DIC_W_READ_B(KS_, SB_)                                                                                       \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
-      bf3_lds_read(fb[j][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)(j * 32 * 64) + pos[KS_]);
-#define DIC_W_PIN(KS_)                                                                                               \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
-    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[i][pl])); }
-#define DIC_W_MFMA(KS_, PA_, PB_)                                                                                    \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
-                                                          __builtin_bit_cast(bf16x8, fb[j][PB_]), acc[i][j], 0, 0, 0);
-#define DIC_W_MFMA_ALL(KS_)                                                                                          \
-  DIC_W_MFMA(KS_, 2, 0) DIC_W_MFMA(KS_, 0, 2) DIC_W_MFMA(KS_, 1, 1) DIC_W_MFMA(KS_, 1, 0) DIC_W_MFMA(KS_, 0, 1) DIC_W_MFMA(KS_, 0, 0)
-  __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
-  DIC_W_READ_A(0, sbase0)
-  int g = 0;
-  for (int j = 0; j < ntl; ++j) {
-    for (int kt = 0; kt < nkt; ++kt, ++g) {
-      const unsigned sb = sbase0 + (unsigned)((g & 1) * STAGE) * 2u, sbn = sbase0 + (unsigned)(((g + 1) & 1) * STAGE) * 2u;
-      // k-step 0: its A fragments were requested one k-step ago; request its B fragments and k-step 1's A fragments
-      DIC_W_READ_B(0, sb) DIC_W_READ_A(1, sb)
-      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-      DIC_W_PIN(0)
-      __builtin_amdgcn_sched_barrier(0);
-      DIC_W_MFMA_ALL(0)
-      __builtin_amdgcn_sched_barrier(0);
-      // k-step 1: B fragments (same registers: the MFMAs above have been issued), then every read of this stage is done
-      DIC_W_READ_B(1, sb)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      DIC_W_PIN(1)
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      DIC_W_MFMA(1, 2, 0)
-      if (g + 1 < total) { DIC_W_READ_A(0, sbn) }
-      DIC_W_MFMA(1, 0, 2) DIC_W_MFMA(1, 1, 1) DIC_W_MFMA(1, 1, 0) DIC_W_MFMA(1, 0, 1) DIC_W_MFMA(1, 0, 0)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- seam: store the tile
-    const int t = xcd_remap(blockIdx.x + j * G, T);
-    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
-    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
-    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
-        if (full) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
-              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
-          cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
-          acc[i][jj][r] = 0.f;
-        }
-      }
-    if (p.ep.stats) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
-        const int n = n0 + jj * 32;
-        if (lane < 32 && n < p.N && tm * BM + wm * 64 < p.M) {      // (wave tiles entirely past M have no row in the table)
-          p.ep.stats[((long long)(tm * 4 + wm) * 2 + 0) * p.N + n] = a;
-          p.ep.stats[((long long)(tm * 4 + wm) * 2 + 1) * p.N + n] = b;
-        }
-      }
-    }
-  }
-#undef DIC_W_READ_A
-#undef DIC_W_READ_B
-#undef DIC_W_PIN
-#undef DIC_W_MFMA
-#undef DIC_W_MFMA_ALL
 }
 
 // 3x3 / stride-1 / pad-1 convolution on 14x14 maps (ResNet layer 3: 36 of the 50 3x3 convolutions) with the input tile's HALO
@@ -1194,40 +780,55 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
 namespace dic {
 
 static int g_last_mtiles = 0;   // M tiles of the most recent launch (row count of the BN partial-sum table)
-static int g_bf3_force = 0;     // benchmarking: 11 / 21 / 22 force the 64x64 / 128x64 / 128x128 workgroup tile
-void gemm_bf3_force_tile(int code);
-
-static int g_bf3_stages = 2;    // benchmarking: ring depth of the 128-wide variants
+// Kernel-selection switches (dic_debug_force_staged_gemm, include/dic.h).  The product library keeps the ones its tests use to
+// compare kernels that the policy below really selects (tile forcing 11 / 21 / 24 / 20, persistent policy 70 / 73 / 79, halo
+// 74 / 75 / 78); the ablations and the parked kernels exist only in the experiments build (-DDIC_EXPERIMENTS).
+static int g_bf3_force = 0;            // 11 / 21 force the 64x64 / 128x64 workgroup tile, 24 the persistent 128x128 kernel wherever its epilogue applies
 static int g_bf3_persist_grid = 224;   // persistent kernels: at most this many workgroups (one per CU).  224 rather than 256: same time per launch
                                        // (operand delivery, not CU count, bounds them) and the main stream's short kernels find free CUs: pipelined step
-                                       // 14.28 -> 14.02 ms; codes 82..89 = 256, 240, ... 144
-static int g_bf3_ws256 = 0;            // codes 80 / 81: 256x128 form of the warp-specialised kernel by policy on / off (default off: measured
-                                       // 4-7 % SLOWER than the 128x128 form on every shape, scripts/bench_bf3_pipe.py; 26 forces it)
-static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
+                                       // 14.28 -> 14.02 ms
 static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the LDS-halo kernel: 0 = off (code 75), 1 = from 128 tiles (78, default), 2 = always (74)
-static int g_bf3_persist_policy = 4;   // benchmarking (codes 70..73, 79): 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
-static int g_bf3_tail_mode = 0; // benchmarking (codes 60..63): 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
-static int g_bf3_ablate = 0;    // benchmarking: 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
+static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
+static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
+#ifdef DIC_EXPERIMENTS
+static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
+static int g_bf3_ws256 = 0;            // codes 80 / 81: 256x128 form of the warp-specialised kernel by policy on / off (measured 4-7 % SLOWER; 26 forces it)
+static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
+static int g_bf3_ablate = 0;           // 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
+#else
+constexpr int g_bf3_stages = 2, g_bf3_ws256 = 0, g_bf3_ws = 1, g_bf3_ablate = 0;
+#endif
 template <int AK, int TM, int TN>
 static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
+#ifdef DIC_EXPERIMENTS
   if constexpr (TM == 2) {
     if (g_bf3_stages == 3) { hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 3>), dim3(blocks), dim3(256), 0, st, p); return; }
   }
+#endif
   hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 2>), dim3(blocks), dim3(256), 0, st, p);
 }
 
-void gemm_bf3_force_tile(int code) {
-  if (code == 42) { g_bf3_stages = 2; return; }
-  if (code == 43) { g_bf3_stages = 3; return; }
-  if (code >= 50 && code <= 53) { g_bf3_ablate = code - 50; return; }
-  if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return; }
-  if (code >= 70 && code <= 73) { g_bf3_persist_policy = code - 70; return; }
-  if (code == 79) { g_bf3_persist_policy = 4; return; }
-  if (code == 74 || code == 75 || code == 78) { g_bf3_halo = code == 74 ? 2 : code == 78 ? 1 : 0; return; }
-  if (code == 76 || code == 77) { g_bf3_ws = code == 76; return; }
-  if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return; }
-  if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return; }      // persistent grids of at most 256, 240, ... 144 workgroups
-  g_bf3_force = code;
+int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this build
+  if (code == 70 || code == 73) { g_bf3_persist_policy = code - 70; return 0; }
+  if (code == 79) { g_bf3_persist_policy = 4; return 0; }
+  if (code == 74 || code == 75 || code == 78) { g_bf3_halo = code == 74 ? 2 : code == 78 ? 1 : 0; return 0; }
+#ifdef DIC_EXPERIMENTS
+  if (code == 76) { g_bf3_ws = 1; return 0; }
+#else
+  if (code == 76) return 0;                                      // warp-specialised persistent kernel: the only form of the product
+#endif
+  if (code == 20 || code == 11 || code == 21 || code == 24) { g_bf3_force = code == 20 ? 0 : code; return 0; }
+#ifdef DIC_EXPERIMENTS
+  if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
+  if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
+  if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
+  if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
+  if (code >= 50 && code <= 53) { g_bf3_ablate = code - 50; return 0; }
+  if (code == 77) { g_bf3_ws = 0; return 0; }
+  if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }
+  if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
+#endif
+  return -1;
 }
 
 static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 1, float* splitk_ws = nullptr,
@@ -1256,7 +857,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // Persistent 128x128 kernel: plain-store epilogue without bias, at least two K tiles.  Policy (scripts/bench_bf3_pipe.py):
   // it wins where a tile is only a few K tiles long and the grid is many rounds deep - the 1x1 expansions 64 -> 256
   // (-12 % per launch at batch 64, -20 % at batch 256), and at batch-256 scale also 128 -> 512 and 256 -> 1024.
-  const bool plain_ep = !p.ep.bias && !p.ep.accumulate && p.ep.act == ACT_NONE;      // what the halo / 256x128 / computing-wave-DMA forms store
+  const bool plain_ep = !p.ep.bias && !p.ep.accumulate && p.ep.act == ACT_NONE;      // what the halo kernel (and the parked forms) store
   const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && p.N % 128 == 0 && (plain_ep || g_bf3_ws);
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
@@ -1270,20 +871,24 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
                 (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
   }
   if (g_bf3_force == 24 || g_bf3_force == 26) persist = persist_ok;
-  // 256x128 form: half as many tiles must still fill the CUs
-  const long long t42 = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128);
-  const int rounds42 = (int)((t42 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
-  const double fill42 = (double)t42 / ((double)rounds42 * g_bf3_persist_grid);
-  bool ws256 = g_bf3_force == 26 && persist_ok && plain_ep;
-  if (g_bf3_force == 0 && g_bf3_ws256 != 0 && persist && g_bf3_ws && plain_ep && t42 >= 512 && fill42 >= 0.75 && fill42 >= fill22 - 0.03 && p.K >= 128) ws256 = true;
+  bool ws256 = false;
+#ifdef DIC_EXPERIMENTS
+  {   // 256x128 form: half as many tiles must still fill the CUs
+    const long long t42 = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128);
+    const int rounds42 = (int)((t42 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
+    const double fill42 = (double)t42 / ((double)rounds42 * g_bf3_persist_grid);
+    ws256 = g_bf3_force == 26 && persist_ok && plain_ep;
+    if (g_bf3_force == 0 && g_bf3_ws256 != 0 && persist && g_bf3_ws && plain_ep && t42 >= 512 && fill42 >= 0.75 && fill42 >= fill22 - 0.03 && p.K >= 128) ws256 = true;
+  }
+#endif
   // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
   const ConvGeom& cg = p.A.g;
   const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && plain_ep && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
                     cg.stride == 1 && cg.pad == 1 && cg.H == 14 && cg.W == 14 && cg.nchw == 0 && cg.C % BK3 == 0 &&
                     p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
   if (halo) persist = true;
-  if (g_bf3_force == 24 || g_bf3_force == 26 || persist) { tmv = 2; tnv = 2; }
-  const bool pipe = tmv == 2 && tnv == 2 && g_bf3_force != 22;       // 128x128 = the deep-pipelined kernel (22: the plain loop)
+  if (persist) { tmv = 2; tnv = 2; }
+  const bool pipe = tmv == 2 && tnv == 2 && g_bf3_force != 22;       // 128x128 (experiments build: the deep-pipelined kernel when not persistent; 22: the plain loop)
   persist = persist && pipe;
   p.mtiles = ceil_div(p.M, 64 * tmv); p.ntiles = ceil_div(p.N, 64 * tnv);
   g_last_mtiles = p.mtiles;
@@ -1314,28 +919,32 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   const bool im = p.A.kind == OPK_IM2COL;
-  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
-  if (persist && ws256 && !halo) {
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
+  if (persist && (halo || !ws256) && (halo || g_bf3_ws) && g_bf3_ablate == 0) {      // the product's 128x128 kernels
+    g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
+    // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
+    const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
+    if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<0>, dim3(grid), dim3(512), 0, st, p);
+    else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
+  }
+#ifdef DIC_EXPERIMENTS
+  else if (persist && ws256 && !halo) {
     p.mtiles = ceil_div(p.M, 256); p.ntiles = ceil_div(p.N, 128);
     g_last_mtiles = ceil_div(p.M, 64);     // statistics rows per 64-row wave tile
     const int T4 = p.mtiles * p.ntiles, grid = ceil_div(T4, ceil_div(T4, g_bf3_persist_grid));
     if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_IM2COL>), dim3(grid), dim3(768), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK>), dim3(grid), dim3(768), 0, st, p);
-  } else if (persist) {
-    g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
-    // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
+  } else if (persist) {                    // ablations of the product kernels, and the persistent kernel without producer waves
+    g_last_mtiles = 2 * p.mtiles;
     const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
-    if (!halo && g_bf3_ws && g_bf3_ablate == 2 && !im) {
-      hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 2>), dim3(grid), dim3(512), 0, st, p);
-    } else if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) {
-      hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 1>), dim3(grid), dim3(512), 0, st, p);
-    } else if (!halo && g_bf3_ws) {
-      if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
-    } else if (halo && g_bf3_ablate == 1) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<1>, dim3(grid), dim3(512), 0, st, p);
+    if (!halo && g_bf3_ws && g_bf3_ablate == 2 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 2>), dim3(grid), dim3(512), 0, st, p);
+    else if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 1>), dim3(grid), dim3(512), 0, st, p);
+    else if (!halo && g_bf3_ws) { if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
+                                  else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p); }
+    else if (halo && g_bf3_ablate == 1) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<1>, dim3(grid), dim3(512), 0, st, p);
     else if (halo && g_bf3_ablate == 2) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<2>, dim3(grid), dim3(512), 0, st, p);
-    else if (halo && g_bf3_ablate == 3) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<3>, dim3(grid), dim3(512), 0, st, p);
-    else if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<0>, dim3(grid), dim3(512), 0, st, p);
+    else if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<3>, dim3(grid), dim3(512), 0, st, p);
     else if (im) hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_IM2COL>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_kernel<OPK_ROWK>), dim3(grid), dim3(256), 0, st, p);
   } else if (pipe && g_bf3_ablate > 0 && !im) {
@@ -1349,9 +958,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (im) hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_IM2COL, 2>), dim3(total), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_pipe_kernel<OPK_ROWK, 2>), dim3(total), dim3(256), 0, st, p);
   } else if (tmv == 2 && tnv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 2>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 2>(p, total, st); }
+  else if (!im && g_bf3_ablate == 1 && tmv == 1) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 1>), dim3(total), dim3(256), 0, st, p);
+  else if (!im && g_bf3_ablate == 2 && tmv == 1) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 2>), dim3(total), dim3(256), 0, st, p);
+#endif
   else if (tmv == 2) { if (im) launch_bf3_variant<OPK_IM2COL, 2, 1>(p, total, st); else launch_bf3_variant<OPK_ROWK, 2, 1>(p, total, st); }
-  else if (!im && g_bf3_ablate == 1) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 1>), dim3(total), dim3(256), 0, st, p);
-  else if (!im && g_bf3_ablate == 2) hipLaunchKernelGGL((gemm_bf3_kernel<OPK_ROWK, 1, 1, 2, 2>), dim3(total), dim3(256), 0, st, p);
   else { if (im) launch_bf3_variant<OPK_IM2COL, 1, 1>(p, total, st); else launch_bf3_variant<OPK_ROWK, 1, 1>(p, total, st); }
   DIC_LAUNCH_CHECK();
   gemm_profile_mark_end(st);

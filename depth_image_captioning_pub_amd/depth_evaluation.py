@@ -7,8 +7,7 @@ copies it to the host every step, depth_models.py:298-299).
 
 Out of scope here as in SURVEY.md section 2: the COCO dataset / annotation files and the pycocoevalcap scorers
 (BLEU / METEOR (Java) / ROUGE / CIDEr, evaluate_metrix.py) - `useData` must be "synthetic" (procedural images, a procedural
-vocabulary), and the scores are computed only when pycocoevalcap happens to be importable; the hypotheses are always
-returned and written next to the checkpoints."""
+vocabulary); no scores are computed, the hypotheses are returned and written next to the checkpoints."""
 from __future__ import annotations
 
 import json
@@ -95,11 +94,8 @@ def Cdepth_evaluation(atten: str, useData: str, config=None, param_files: Option
         hypos_id = np.concatenate(hypos_id)
         hypos_word = ids_to_captions(hypos_id, id_to_word)
         results[key] = {"hypotheses": hypos_word, "ids": hypos_id}
-        try:                                                                                # :178-184 (needs pycocoevalcap + Java)
-            from pycocoevalcap.bleu.bleu import Bleu  # noqa: F401
-            results[key]["scores"] = "pycocoevalcap present: plug evaluate_metrix.score here"
-        except Exception:
-            results[key]["scores"] = None
+        # depth_evaluation.py:178-184 scores the hypotheses with BLEU / METEOR / CIDEr (pycocoevalcap + Java): out of scope
+        #  - the hypotheses are the product of this path.
     with open(os.path.join(save_directory, f"{useData}_hypotheses.json"), "w") as f:
         json.dump({k: v["hypotheses"] for k, v in results.items()}, f)
     return results

@@ -23,3 +23,27 @@ def host_cores() -> int:
         except Exception:
             pass
     return max(1, n)
+
+
+def visible_gpus():
+    """Number of GPUs this process would see, WITHOUT any HIP / HSA call (a parent that has touched the runtime must not fork
+    GPU ranks): the device-visibility environment variables if one is set, else the KFD topology in sysfs (nodes with SIMDs
+    are GPUs; no KFD topology at all = no AMD GPU driver = 0).  None only when the topology exists but cannot be read - the
+    caller then lets the ranks themselves find out."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return 0
+    try:
+        n = 0
+        for node in os.listdir(root):
+            for line in open(os.path.join(root, node, "properties")):
+                key, _, val = line.partition(" ")
+                if key == "simd_count" and int(val) > 0:
+                    n += 1
+        return n
+    except Exception:
+        return None

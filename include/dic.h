@@ -330,26 +330,19 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
 /* ---- measurement aid (bench.py roofline): per-launch HIP events around every MFMA contraction launch,
  *      recorded on the launch stream; dic_profile_end synchronises and returns, per kernel instantiation
  *      (key = 1000*(LDS-DMA kernel) + 100*(tile==128) + 10*A_kind + B_kind; 2000 + 10*A_kind = bf16x3 kernel), total milliseconds, algorithmic FLOPs and launches. */
-/* Benchmarking / ablation switches (process-global, used by scripts/ only; results stay correct under every code):
- *   0 / 1        LDS-DMA kernels (default) / every exact-fp32 contraction on the register-staged kernel (v1)
- *   11 21 22 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / 128x128 (plain loop) / policy default
- *   23 24 26     ... forced to the deep-pipelined 128x128 kernel / its persistent form (wherever its epilogue applies) / the 256x128 form
- *   80 81        256x128 persistent form by policy on / off (default: measured slower)
- *   82..89       persistent kernels use at most 256 / 240 / 224 (default) / ... / 144 workgroups
- *   42 43        ring depth 2 / 3 of the 128-wide bf16x3 variants
- *   50 51 52 53  ablations of the kernel selected by 11 / 23 / the halo kernel: full / no DMA in the loop / ... (scripts/bench_bf3_*ablate*.py)
- *   70..73 79    persistent kernel by policy: never / K <= 64 / + K <= 256 on >= 3072-tile grids / 1x1 convolutions by CU fill / + gathered convolutions (default)
- *   76 77        persistent kernel warp-specialised, 4 compute + 4 DMA waves (default) / DMA issued by the computing waves
+/* Kernel-selection switches (process-global; results stay correct under every code).  libdic_hip.so knows only the codes
+ * its own tests use to put two PRODUCT kernels side by side:
+ *   11 21 24 20  bf16x3 workgroup tile forced to 64x64 / 128x64 / the persistent warp-specialised 128x128 kernel (wherever its
+ *                epilogue applies) / policy default
+ *   70 73 79     persistent kernel by policy: never / 1x1 convolutions by CU fill / + gathered convolutions (default)
  *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
- *   60 61 62 63  remainder-tile K split: default / off / also on large grids / at most 4 slices
- *   120 121      tail fix-up and BatchNorm finalize in separate launches / fused (default)
- *   122 123      ResNet stem (bf16x3 mode) on the exact-fp32 gather kernel / strip formulation (default)
- *   140 141      decoder forward loop: one launch pair per step (default) / one persistent launch for all steps
- *   142 143      persistent loop placement: a row group's 16 chunk workgroups on one XCD (default) / chunks 2x, 2x+1 on XCD x
- *   130..134     depth-encoder layer 1: generic MFMA gather path / packed-FMA kernels with 256, 512 (default), 768, 1024 workgroups
- * Unknown codes are rejected (DIC_ERR_ARG).
+ *   76           accepted, no effect (the persistent kernel's only form here is the warp-specialised one)
+ * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
+ * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
+ * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes
+ * listed in csrc/api.hip and csrc/gemm_bf3.hip); scripts/ load it with DIC_LIB=experiments, the product never does.
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,
- * 4 = deep-pipelined 128x128, 5 = persistent 128x128, 6 = LDS-halo 3x3. */
+ * 5 = persistent warp-specialised 128x128, 6 = LDS-halo 3x3 (experiments: 4 = deep-pipelined, 7 = 256x128, 8 = computing-wave DMA). */
 int dic_debug_force_staged_gemm(int on);
 int dic_profile_begin(void);
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);

@@ -27,21 +27,32 @@ def test_loader_fails_loudly_when_library_missing(monkeypatch, tmp_path):
 
 
 def test_unknown_debug_switch_is_rejected():
-    """The benchmarking switches are process-global state (include/dic.h): an unknown code must be an error, not a silent
-    change of some other switch (round 2: code 182 fell through to the exact-fp32 kernel selector).  No GPU call involved."""
+    """The kernel-selection switches are process-global state (include/dic.h): an unknown code must be an error, not a silent
+    change of some other switch (round 2: code 182 fell through to the exact-fp32 kernel selector).  The product library only
+    knows the codes its tests use; ablations and parked kernels (23 / 26 / 77 bf16x3 forms, 50..53 ablations, 141 persistent
+    decoder loop, 1 register-staged kernel everywhere) belong to the experiments build.  No GPU call involved."""
     lib = ctypes.CDLL(build.build())
     lib.dic_last_error.restype = ctypes.c_char_p
-    for code in (9999, 182, -5, 29):
+    for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 121):
         assert lib.dic_debug_force_staged_gemm(code) != 0, code
         assert b"unknown" in lib.dic_last_error()
-    for code in (20, 78, 76, 73, 79):          # the defaults of the bf16x3 policy switches: accepted, no effect on results
+    for code in (11, 21, 24, 70, 75, 74, 20, 78, 76, 73, 79):          # (ending on the defaults)
         assert lib.dic_debug_force_staged_gemm(code) == 0, code
 
 
 def test_device_code_has_no_defective_packed_fp32_forms():
-    """build.py audits the gfx950 assembly of every source for packed fp32 instructions whose low result takes the high half of
-    src1 (wrong results next to other kernels' waves, scripts/diag_pk_fp32_opsel.py): none outside the two exempt files."""
+    """build.py audits the gfx950 assembly of every source linked into libdic_hip.so for packed fp32 instructions whose low result
+    takes the high half of src1 (wrong results next to other kernels' waves, scripts/diag_pk_fp32_opsel.py): none, no exemptions."""
     build.build()
+    assert build._AUDIT_EXEMPT == ()
     found = build.audit_packed_fp32()
-    assert found and all(n == 0 for k, n in found.items() if k not in build._AUDIT_EXEMPT), found
-    assert found.get("probe_pk_fp32", 0) > 0        # the reproducer really contains them (the audit sees what it should)
+    assert found and all(n == 0 for n in found.values()), found
+    assert "probe_pk_fp32" not in found and "decoder_persist" not in found      # (experiments library only)
+
+
+def test_product_library_holds_no_parked_or_probe_code():
+    """The parked kernels and the defect reproducer are built into libdic_experiments.so only (build.py --experiments)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
+    for needle in ("probe", "pipe_kernel", "persist_kernel", "ws256", "decoder_fwd_persistent", "dic_debug_decoder_stamps"):
+        assert needle not in out, needle

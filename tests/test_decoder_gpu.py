@@ -124,44 +124,6 @@ def test_compact_49_cell_layout_vs_oracle(lib, lengths, vocab, seed, train):
     _assert_close("grad.features(7x7)", dfeat, g196, 1e-3)
 
 
-@pytest.mark.parametrize("cells", [49, 196])
-@pytest.mark.parametrize("lengths", [[21] * 64, [13, 13, 12, 9, 9, 8, 5, 2], [7] * 5])
-def test_persistent_forward_loop_vs_oracle_and_per_step(lib, lengths, cells):
-    """The opt-in persistent forward loop (csrc/decoder_persist.hip: one launch for all T steps, 256 co-resident
-    workgroups exchanging partial gate pre-activations through write-through stores + per-group counters) against the oracle
-    (logits / alphas 1e-4, argmax identical) and against the default per-step launches (1e-5: only the summation order of
-    the gate pre-activation differs), full (64 rows), ragged and partial-group batches, both layouts; the hand-off status word
-    must stay clear and the backward must accept the tape it leaves."""
-    vocab, seed = 300, 91
-    w, f_rgb, f_dep, caps, lens = _inputs(lengths, vocab, seed, replicate=True)
-    B, tmax = len(lens), max(lens) - 1
-    drop = syn.dropout_multiplier(B, tmax, 0.5, seed=seed)
-    ref, _, al_ref = orc.decoder_forward(w, f_rgb, f_dep, caps, lens, drop)
-
-    def cut(f):
-        return f if cells == 196 else f.reshape(B, 14, 14, -1)[:, ::2, ::2].reshape(B, 49, -1).contiguous()
-    out = {}
-    try:
-        for name, code in (("per_step", 140), ("persistent", 141)):
-            lib.dic_debug_force_staged_gemm(code)
-            logits, alphas, tape = native.decoder_forward(_to_dev(w), cut(f_rgb).to(DEV), cut(f_dep).to(DEV), caps.to(DEV), lens,
-                                                          drop.to(DEV))
-            loss, dl, da = native.caption_loss(logits, native.pack_targets(caps.to(DEV), lens), alphas)
-            grads, _ = native.decoder_backward(tape, dl, da)
-            torch.cuda.synchronize()
-            out[name] = (logits.clone(), alphas.clone(), float(loss.item()), {k: v.clone() for k, v in grads.items()})
-    finally:
-        lib.dic_debug_force_staged_gemm(140)
-    _assert_close("logits", out["persistent"][0], ref, 1e-4)
-    _assert_close("alphas", out["persistent"][1], al_ref, 1e-4)
-    assert torch.equal(out["persistent"][0].argmax(1).cpu(), ref.argmax(1))
-    _assert_close("logits vs per-step", out["persistent"][0], out["per_step"][0], 1e-5)
-    assert abs(out["persistent"][2] - out["per_step"][2]) <= 1e-5
-    for k in w:
-        if not k.endswith("full_att.bias"):
-            _assert_close("grad." + k, out["persistent"][3][k], out["per_step"][3][k], 1e-4)
-
-
 def test_base_hard_decoder_vs_oracle(lib):
     """base-hard (RNNDecoderWithHardAttention, base_caption_models.py:257-508) = the depth-hard decoder without depth
     features: forward (Gumbel-softmax, temp), eval_forward (Gumbel-max) and the gradients vs the oracle with zero depth
