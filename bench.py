@@ -24,7 +24,9 @@ The JSON line also carries
   cpu_baseline - the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample,
   parity       - same-run parity gate: the first oracle step of the cpu_baseline leg (initial weights,
                  batch --cpu-batch, explicit dropout mask) against one GPU step on the same tensors: |loss difference|
-                 (bar 1e-4) and teacher-forced token-id argmax over all packed tokens (bar: identical).
+                 (bar 1e-4) and teacher-forced token-id argmax over all packed tokens (bar: identical on every row the
+                 oracle's own fp32 and fp64 evaluations decide alike, `rows_undecidable_by_oracle` <= 2 %); a failed gate
+                 makes bench.py exit non-zero.
 """
 from __future__ import annotations
 
@@ -143,11 +145,18 @@ def cpu_baseline(sample_b: int, iters: int):
     first = None
     for it in range(iters + 1):
         t0 = time.perf_counter()
+        if it == 0:       # (untimed) the same step in fp64: what the fp32 oracle itself can decide, see parity_gate
+            d64 = lambda d: {k: v.double() for k, v in d.items()}                                    # noqa: E731
+            feats64 = orc.resnet152_features(d64(rn), imgs.double(), train_bn=True)
+            loss64, packed64 = orc.step_logits(d64(dec), d64(enc), d64(st), feats64, depth.double(), caps, lens, drop.double())
+            del feats64
+            t0 = time.perf_counter()
         feats = orc.resnet152_features(rn, imgs, train_bn=True)
         loss, packed, _, gd, ge = orc.train_step_soft(dec, enc, st, feats, depth, caps, lens, drop)
         if it == 0:       # initial weights: the step the GPU leg of the parity gate repeats
             first = {"loss": float(loss), "packed": packed.clone(), "imgs": imgs, "depth": depth, "caps": caps,
-                     "lens": lens, "drop": drop, "batch": sample_b}
+                     "lens": lens, "drop": drop, "batch": sample_b, "loss64": float(loss64),
+                     "undecidable": orc.rows_undecidable_by_oracle(packed, packed64)}
         params = {**dec, **enc}
         orc.adamw_step(params, {**gd, **ge}, m, v2, step=it + 1)
         times.append(time.perf_counter() - t0)
@@ -172,24 +181,27 @@ def parity_gate(first, dev: str, conv_mode: str, compact: bool):
     ref = first["packed"]
     mism = logits.argmax(1) != ref.argmax(1)
     dmax = float((logits - ref).abs().max())
-    top2 = ref.topk(2, dim=1).values
-    in_band = (top2[:, 0] - top2[:, 1]) <= 2.0 * (logits - ref).abs().max(dim=1).values   # rows no fp32 evaluation can decide
+    undec = first["undecidable"]          # rows the ORACLE cannot decide (its fp32 vs fp64 evaluation); nothing of the GPU run enters
     diff = abs(float(loss.item()) - first["loss"])
-    outside = int((mism & ~in_band).sum())
+    outside = int((mism & ~undec).sum())
+    n_undec = int(undec.sum())
     return {"batch": first["batch"], "tokens": int(mism.numel()), "loss_gpu": round(float(loss.item()), 6),
             "loss_oracle": round(first["loss"], 6), "loss_abs_diff": diff, "loss_tolerance": 1e-4,
+            "loss_oracle_fp32_vs_fp64": abs(first["loss"] - first["loss64"]),
             "argmax_equal": int(mism.sum()) == 0, "argmax_mismatches": int(mism.sum()),
-            "max_abs_dlogit": dmax, "rows_inside_rounding_band": int(in_band.sum()),
-            "argmax_mismatches_outside_rounding_band": outside,
-            "ok": bool(diff <= 1e-4 and outside == 0),
+            "rows_undecidable_by_oracle": n_undec,
+            "argmax_mismatches_on_decidable_rows": outside,
+            "max_abs_dlogit": dmax,
+            "ok": bool(diff <= 1e-4 and outside == 0 and n_undec <= mism.numel() // 50),
             "resnet_conv_mode": conv_mode, "annotation_cells": 49 if compact else 196,
             "what": "teacher-forced token-id argmax over all packed logits rows and the training loss of one full step "
                     "(ResNet-152 fwd, depth encoder, decoder, CE + regulariser) vs the CPU oracle on the same inputs, "
-                    "same explicit dropout mask.  155 batch-statistics BatchNorm layers put the fp32 oracle's own "
-                    "ResNet features ~2e-3 from an fp64 evaluation (and the HIP path's equally), which reaches the "
-                    "logits (max_abs_dlogit); a row whose oracle top-2 margin is within 2x its own max |d logit| is inside "
-                    "the rounding band.  tests/test_fullsize_parity_gpu.py holds the stage-wise proof (identical argmax on every row "
-                    "and 1e-6-level logits when both sides see the same ResNet features)"}
+                    "same explicit dropout mask.  Bar: loss within 1e-4 and an identical argmax on every row the oracle "
+                    "itself can decide; a row is undecidable when the oracle's own fp64 evaluation of the step picks another "
+                    "token or its fp32 top-2 margin is within 2x its own |logit32 - logit64| on that row (155 batch-statistics "
+                    "BatchNorm layers put any fp32 evaluation of the ResNet ~2e-3 from fp64) - at most 2 % of the rows.  "
+                    "tests/test_fullsize_parity_gpu.py holds the stage-wise proof (identical argmax on every row and "
+                    "1e-6-level logits when both sides see the same ResNet features).  bench.py exits non-zero when ok is false"}
 
 
 def bench_dpt(args, dev: str, world: int, rank: int):
@@ -327,11 +339,21 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("DIC_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev), timeout=limit)
         else:
-            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
         pg = torch.distributed.group.WORLD
+        # communicator self-check before anything is timed: a broken or mismatched communicator must fail here, loudly
+        # (bounded by the process-group timeout), not hang inside the measured region
+        probe = torch.full((1,), float(rank + 1), device=dev)
+        torch.distributed.all_reduce(probe)
+        torch.cuda.synchronize()
+        if float(probe.item()) != world * (world + 1) / 2:
+            raise SystemExit(f"bench.py: all-reduce self-check failed on rank {rank}: got {float(probe.item())}, "
+                             f"expected {world * (world + 1) / 2} over {world} ranks")
 
     from depth_image_captioning_pub_amd import build as dic_build, _lib
     if not os.path.exists(_lib.LIB_PATH):
@@ -349,6 +371,7 @@ def main():
         return bench_dpt(args, dev, world, rank)
     B = args.batch
     trainer = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=args.conv_mode)
+    trainer_numel = trainer.flat.total
     if args.reference_cells:
         trainer.compact_ok = False
     imgs = syn.rgb_images(B, seed=123 + rank).to(dev)
@@ -421,6 +444,7 @@ def main():
                "ms_per_step": round(e2 / 5 * 1e3, 3), "steps": 5, "warmup": 2}
         del tr2
     result = None
+    parity_failed = False
     if rank == 0:
         top = prof[0]
         ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
@@ -473,13 +497,21 @@ def main():
         result["config"]["ranks"] = world
         result["config"]["collective"] = (f"{backend} all-reduce of 2 gradient buckets over {world} ranks" if world > 1
                                           else "none (single rank)")
+        if world > 1:
+            result["config"]["collective_ranks"] = torch.distributed.get_world_size(pg)
+            result["config"]["collective_self_check"] = "1-element all-reduce before the warm-up: ok"
+            result["config"]["gradient_bytes_per_step"] = int(4 * trainer_numel)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"], first = cpu_baseline(args.cpu_batch, args.cpu_iters)
             result["parity"] = parity_gate(first, dev, args.conv_mode, not args.reference_cells)
         print(json.dumps(result), flush=True)
+        parity_failed = bool(result.get("parity")) and not result["parity"]["ok"]
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if parity_failed:       # a fast step whose results differ from the reference's is not a result
+        print("bench.py: the same-run parity gate FAILED (see \"parity\" in the line above)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -48,10 +48,11 @@ class _DptFrontEnd:
     estimator predicts the depth map of every image, which is standardised, resized to 224x224 and stored under its key
     (the reference keys a CPU dict by the joined caption strings); later epochs fetch whole batches from the cache."""
 
-    def __init__(self, config, capacity: int):
+    def __init__(self, config, capacity: int, share: "_DptFrontEnd" = None):
         from .DPT_model import DPT_Depthestimator
         from ..util import DepthCache
-        self.dpt = DPT_Depthestimator(getattr(config, "dpt_config", None)).to(config.device)       # :121,126-127 (frozen, eval)
+        # (the validation front-end shares the frozen estimator and owns the second cache, depth_dic_val: depth_train.py:258-275)
+        self.dpt = share.dpt if share is not None else DPT_Depthestimator(getattr(config, "dpt_config", None)).to(config.device)   # :121,126-127 (frozen, eval)
         self.cache = DepthCache(capacity, device=config.device)
         self.forwards = self.hits = 0
 
@@ -74,26 +75,33 @@ def _gumbel_draws(tmax: int, batch: int, epoch: int, iteration: int, rank: int, 
     return syn.gumbel_uniforms(tmax, batch, seed=seed)
 
 
-def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None):
+def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None, depth_branch: bool = True,
+           tag: str = None, save_directory: str = None):
+    """Shared loop of train_Cdepth_{soft,hard} and (depth_branch=False: no depth encoder, decoder-only optimiser, two
+    checkpoints) of train_base_{soft,hard} (Base_caption_model/base_train.py:24-234, 248-460)."""
     config = config or ConfigTrain()
     if useData != "synthetic":
         raise DicError(f"useData={useData!r}: the MSCOCO / original-dataset loaders and the vocabulary pickle are outside "
                        "this build's scope (SURVEY.md 8f) and not available offline; use useData='synthetic' "
                        "(config.use_dpt = True adds the DPT depth front-end of BASELINE config 5)")
-    save_directory = config.save_directory_Cdep_hard if hard else config.save_directory_Cdep_soft
+    if save_directory is None:
+        save_directory = config.save_directory_Cdep_hard if hard else config.save_directory_Cdep_soft
     os.makedirs(save_directory, exist_ok=True)
-    tag = "depth_hard" if hard else "depth_soft"
+    tag = tag or ("depth_hard" if hard else "depth_soft")
     train_loss_file = f"{save_directory}/{tag}_train_loss_{useData}{ext}.csv"
     val_loss_file = f"{save_directory}/{tag}_val_loss_{useData}{ext}.csv"
     rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
     trainer = CaptionTrainer(config.vocab_size, device=config.device, seed=123 + int(ext), lr=config.lr, hard=hard,
-                             dropout=config.dropout, lam=lam, process_group=process_group)
+                             dropout=config.dropout, lam=lam, process_group=process_group, use_depth=depth_branch,
+                             conv_mode=getattr(config, "conv_mode", "fp32"))
     dev = config.device
     temp = torch.tensor(1.0)
     val_loss_best = float("inf")
     history = []
-    use_dpt = bool(getattr(config, "use_dpt", False))        # BASELINE config 5: depth maps from the DPT front-end
+    use_dpt = depth_branch and bool(getattr(config, "use_dpt", False))        # BASELINE config 5: depth maps from the DPT front-end
+    n_val = max(1, config.iters_per_epoch // 4)
     front = _DptFrontEnd(config, config.iters_per_epoch * config.batch_size) if use_dpt else None
+    front_val = _DptFrontEnd(config, n_val * config.batch_size, share=front) if use_dpt else None
     for epoch in range(config.num_epochs):
         if hard and epoch % config.temp_sch == 0:                       # depth_train.py:481-483
             temp = temp_anneal(epoch)
@@ -105,7 +113,7 @@ def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None
                                                                               0 if use_dpt else 1000 * epoch, raw=use_dpt)):
                 if use_dpt:
                     imgs, depth = front.depth_maps(epoch, [f"{it}:{i}" for i in range(len(lens))], imgs.to(dev))
-                yield it, imgs.to(dev), depth.to(dev), caps.to(dev), lens
+                yield it, imgs.to(dev), (depth.to(dev) if depth_branch else None), caps.to(dev), lens
         # two batches of look-ahead: the frozen RGB encoder runs ahead of the step on side streams (engine.prefetch_features)
         ahead, stream_it = [], on_device()
         for nxt in stream_it:
@@ -132,11 +140,15 @@ def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None
                 print(f"{epoch}, {train_loss}", file=f)
         # validation: eval-mode encoders, dropout off; soft = CE + regulariser (depth_train.py:248-292), hard =
         # decoder.eval_forward (Gumbel-max one-hot attention) with CE only (depth_train.py:555-610)
+        # With the DPT front-end the validation images go through it too: predicted in epoch 0, read from the validation cache
+        # (the reference's depth_dic_val) afterwards (depth_train.py:258-275) - same distribution as the training depth maps.
         val_losses = []
-        for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank,
-                                                                          max(1, config.iters_per_epoch // 4), 777)):
+        for it, (imgs, depth, caps, lens) in enumerate(_synthetic_batches(config, rank, n_val, 777, raw=use_dpt)):
+            if use_dpt:
+                imgs, depth = front_val.depth_maps(epoch, [f"v{it}:{i}" for i in range(len(lens))], imgs.to(dev))
             u = _gumbel_draws(max(lens) - 1, len(lens), epoch, 100000 + it, rank, int(ext)).to(dev) if hard else None
-            val_losses.append(trainer.eval_loss(imgs.to(dev), depth.to(dev), caps.to(dev), lens, gumbel_u=u))
+            val_losses.append(trainer.eval_loss(imgs.to(dev), depth.to(dev) if depth_branch else None, caps.to(dev), lens,
+                                                gumbel_u=u))
         val_loss = float(torch.stack(val_losses).mean().item())
         history.append((train_loss, val_loss))
         if rank == 0:
@@ -147,9 +159,14 @@ def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None
                 sd = trainer.state_dicts()
                 torch.save(sd["encoder"], f"{save_directory}/{tag}_encoder_best_{useData}{ext}.pth")
                 torch.save(sd["decoder"], f"{save_directory}/{tag}_decoder_best_{useData}{ext}.pth")
-                torch.save(sd["depth_encoder"], f"{save_directory}/{tag}_D_encoder_best_{useData}{ext}.pth")
+                if depth_branch:
+                    torch.save(sd["depth_encoder"], f"{save_directory}/{tag}_D_encoder_best_{useData}{ext}.pth")
+    if stats is not None:
+        stats.update(prefetch_dropped=trainer.prefetch_dropped)
     if stats is not None and front is not None:
-        stats.update(dpt_forwards=front.forwards, cache_hits=front.hits, cache_entries=len(front.cache.slot))
+        stats.update(dpt_forwards=front.forwards, cache_hits=front.hits, cache_entries=len(front.cache.slot),
+                     val_dpt_forwards=front_val.forwards, val_cache_hits=front_val.hits,
+                     val_cache_entries=len(front_val.cache.slot))
     return history
 
 

@@ -21,6 +21,8 @@ class ConfigTrain(object):
         self.temp_sch = 10              # :26 temperature re-annealed every 10 epochs (hard path)
         self.device = "cuda:0"          # :68
         self.moving_avg = 100           # :71
+        self.save_directory_soft = self.cwd + "/exp_result/base_soft"           # config.py:45 (base-soft; base_train.py:253 also puts base-hard here)
+        self.save_directory_hard = self.cwd + "/exp_result/base_hard"           # :51
         self.save_directory_Cdep_soft = self.cwd + "/exp_result/CNN_depth_soft"
         self.save_directory_Cdep_hard = self.cwd + "/exp_result/CNN_depth_hard"
         # synthetic-run knobs (no dataset / vocabulary ships with the reference)

@@ -1,7 +1,9 @@
 """Fused depth-soft / depth-hard training step on one MI355X, data-parallel across the GPUs of a node.
 
 Counterpart of the inner loop of train_Cdepth_soft / train_Cdepth_hard
-(Captioning_models/Depth_caption_model/depth_train.py:168-229, 500-560): same call order, same
+(Captioning_models/Depth_caption_model/depth_train.py:168-229, 500-560) and, with `use_depth=False`, of train_base_soft /
+train_base_hard (Captioning_models/Base_caption_model/base_train.py:136-175, 363-403: no depth branch, the optimiser
+holds the decoder only - BASELINE config 1): same call order, same
 train/eval-mode semantics (incl. quirk Q1: the frozen ResNet normalises with batch statistics while
 training), same loss, same AdamW update - every tensor operation runs in libdic_hip.so.
 
@@ -72,6 +74,15 @@ def shard_rows(n_rows: int, world: int, rank: int) -> slice:
         raise DicError(f"global batch {n_rows} is not divisible by world size {world}")
     per = n_rows // world
     return slice(rank * per, (rank + 1) * per)
+
+
+def gradient_scales(n_local_tokens: int, world: int, global_tokens: Optional[int] = None):
+    """(cross-entropy gradient scale, regulariser gradient scale) of one rank such that the SUM of the ranks' gradients is the
+    gradient of the single-device loss on the global batch: the cross-entropy is a mean over the packed tokens, so rank r
+    carries its share N_r / sum_r N_r of them (= 1 / world for equal-length batches, the default when `global_tokens` is not
+    given); the attention regulariser is a mean over [B, L] with equal rows per rank: 1 / world."""
+    ce = 1.0 / world if global_tokens is None else n_local_tokens / float(global_tokens)
+    return ce, 1.0 / world
 
 
 def exchange_gradients(flat_grad: torch.Tensor, spans, group, between=None) -> None:
@@ -171,7 +182,7 @@ class CaptionTrainer:
                  depth_init: Optional[Dict[str, torch.Tensor]] = None,
                  depth_state: Optional[Dict[str, torch.Tensor]] = None,
                  resnet_init: Optional[Dict[str, torch.Tensor]] = None,
-                 process_group=None, conv_mode: str = "fp32"):
+                 process_group=None, conv_mode: str = "fp32", use_depth: bool = True):
         if not torch.cuda.is_available():
             raise DicError("CaptionTrainer needs a GPU: the product path has no CPU fallback")
         self.device = torch.device(device)
@@ -179,12 +190,13 @@ class CaptionTrainer:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        self.use_depth = use_depth     # False: base-soft / base-hard (base_train.py): no depth encoder, decoder-only optimiser
         dec = decoder_init if decoder_init is not None else syn.decoder_weights(vocab, seed=seed)
-        if depth_init is None:
+        if use_depth and depth_init is None:
             depth_init, depth_state = syn.depth_encoder_weights(seed=seed + 1)
         rn = resnet_init if resnet_init is not None else syn.resnet152_weights(seed=seed + 2, layers=resnet_layers)
         self.dec_names = [k for k, _ in native.DECODER_FIELDS]
-        self.enc_names = [k for k, _ in native.DEPTH_FIELDS]
+        self.enc_names = [k for k, _ in native.DEPTH_FIELDS] if use_depth else []
         merged = {("decoder." + k): dec[k] for k in self.dec_names}
         merged.update({("depth_encoder." + k): depth_init[k] for k in self.enc_names})
         self.flat = FlatParams(merged, self.device)
@@ -193,8 +205,8 @@ class CaptionTrainer:
         self.dec_g = {k: self.flat.view(self.flat.grad, "decoder." + k) for k in self.dec_names}
         self.enc_g = {k: self.flat.view(self.flat.grad, "depth_encoder." + k) for k in self.enc_names}
         self.dec_span = self.flat.span(["decoder." + k for k in self.dec_names])
-        self.enc_span = self.flat.span(["depth_encoder." + k for k in self.enc_names])
-        self.enc_state = {k: v.to(self.device).contiguous() for k, v in depth_state.items()}
+        self.enc_span = self.flat.span(["depth_encoder." + k for k in self.enc_names]) if use_depth else None
+        self.enc_state = {k: v.to(self.device).contiguous() for k, v in depth_state.items()} if use_depth else {}
         self.rn_w = {k: v.to(self.device).contiguous() for k, v in rn.items()}
         # every BatchNorm running statistic of the frozen ResNet lives in ONE flat buffer (the dict holds views), so that
         # the update of a whole batch is one dic_bn_ema_update launch (see _PrefetchSlot)
@@ -225,6 +237,7 @@ class CaptionTrainer:
         self.slot_next = 0
         self.queue: List[tuple] = []   # FIFO of (imgs tensor, slot, done-event) in launch (= batch) order
         self.side_done = None          # completion event of the newest side-stream forward (see _resnet_eager)
+        self.prefetch_dropped = 0      # prefetched forwards discarded because the caller left the announced batch order
         self.feat_copy: Optional[torch.Tensor] = None
         # each forward is ~620 launches (9 ms of host enqueue); it is captured once per (batch shape, slot) into a hipGraph
         # and replayed (0.2 ms).  DIC_RESNET_GRAPH=0 keeps eager launches.
@@ -290,8 +303,23 @@ class CaptionTrainer:
     def _take_prefetched(self, imgs: torch.Tensor):
         """Features of `imgs` if its forward is the oldest one in flight: waits for it on the current stream and applies
         its BatchNorm running-statistic update."""
-        if not self.queue or self.queue[0][0] is not imgs:
+        if not self.queue:
             return None
+        if self.queue[0][0] is not imgs:
+            # The caller left the announced order (another tensor object, a skipped or re-ordered batch, an exception mid-epoch).
+            # Forwards launched for batches that are not consumed now are DISCARDED - their BatchNorm deltas are never applied,
+            # exactly as if those forwards had not run (the reference only runs the encoder on batches it trains on) - so the
+            # running statistics stay in consumption order and the slots are free again for the following prefetches.
+            pos = next((i for i, (q, _, _) in enumerate(self.queue) if q is imgs), len(self.queue))
+            for _, _, done in self.queue[:pos]:
+                torch.cuda.current_stream().wait_event(done)      # (its buffers must be idle before the slot is reused)
+            self.prefetch_dropped += pos
+            import warnings
+            warnings.warn(f"CaptionTrainer: {pos} prefetched ResNet forward(s) discarded - train_step received a batch that "
+                          "was not the next announced one (next_imgs)", RuntimeWarning, stacklevel=3)
+            self.queue = self.queue[pos:]
+            if not self.queue:
+                return None
         _, slot, done = self.queue.pop(0)
         torch.cuda.current_stream().wait_event(done)
         native.bn_ema_update(self.rn_stats, slot.delta, 0.1)
@@ -316,19 +344,22 @@ class CaptionTrainer:
     # ---- pieces -----------------------------------------------------------------------------
     def _compact(self, imgs, depth_map) -> bool:
         """Use the 49-cell layout for this batch? (soft attention, 224x224 RGB and depth inputs)"""
-        return (self.compact_ok and not self.hard and depth_map is not None and tuple(depth_map.shape[-2:]) == (224, 224)
-                and (imgs is None or tuple(imgs.shape[-2:]) == (224, 224)))
+        if self.use_depth and (depth_map is None or tuple(depth_map.shape[-2:]) != (224, 224)):
+            return False
+        return self.compact_ok and not self.hard and (imgs is None or tuple(imgs.shape[-2:]) == (224, 224))
 
-    def encode(self, imgs: torch.Tensor, depth_map: torch.Tensor, train: bool):
+    def encode(self, imgs: torch.Tensor, depth_map: Optional[torch.Tensor], train: bool):
         compact = self._compact(imgs, depth_map)
         feats = self._resnet_eager(imgs, train, compact)                                    # depth_train.py:179
+        if not self.use_depth:
+            return feats, None, None
         fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), train,
                                                    workspace=self.enc_ws, compact=compact)   # :204-206
         self.enc_ws = dtape.workspace
         self.depth_fwd_count += int(train)
         return feats, fdep, dtape
 
-    def train_step(self, imgs: torch.Tensor, depth_map: torch.Tensor, captions: torch.Tensor, lengths: Sequence[int],
+    def train_step(self, imgs: torch.Tensor, depth_map: Optional[torch.Tensor], captions: torch.Tensor, lengths: Sequence[int],
                    drop_mult: Optional[torch.Tensor] = None, gumbel_u: Optional[torch.Tensor] = None,
                    temp: float = 1.0, precomputed_features: Optional[torch.Tensor] = None,
                    next_imgs=None, global_tokens: Optional[int] = None,
@@ -358,16 +389,15 @@ class CaptionTrainer:
                     if k >= len(self.queue):        # (entry k of the queue is batch i+1+k when the caller keeps this order)
                         self.prefetch_features(nxt, compact=self._compact(nxt, depth_map))
             self._mark("resnet152_fwd")
+        else:                                       # decoder/depth-encoder-only step (tests)
+            feats = precomputed_features
+            compact = feats.shape[1] == native.L_COMPACT
+        fdep = dtape = None
+        if self.use_depth:
             fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
                                                        workspace=self.enc_ws, compact=compact)   # :204-206
             self.enc_ws = dtape.workspace
-        else:                                       # decoder/depth-encoder-only step (tests)
-            feats = precomputed_features
-            fdep, dtape = native.depth_encoder_forward(self.enc_w, self.enc_state, depth_map.detach(), True,
-                                                       workspace=self.enc_ws,
-                                                       compact=feats.shape[1] == native.L_COMPACT)
-            self.enc_ws = dtape.workspace
-        self.depth_fwd_count += 1
+            self.depth_fwd_count += 1
         self._mark("depth_encoder_fwd")
         if drop_mult is None and self.p_drop > 0:
             drop_mult = native.dropout_mask((B, tmax, native.D_HID), self.p_drop, self.drop_seed, self.rng_offset,
@@ -380,15 +410,17 @@ class CaptionTrainer:
         self._mark("decoder_fwd")
         targets = native.pack_targets(captions, lengths)                                     # :210-213
         nworld = virtual_world if virtual_world is not None else self.world
-        n_local = int(targets.shape[0])
-        ce_scale = 1.0 / nworld if global_tokens is None else n_local / float(global_tokens)
+        ce_scale, reg_scale = gradient_scales(int(targets.shape[0]), nworld, global_tokens)
         loss, dlogits, dalphas = native.caption_loss(logits, targets, None if self.hard else alphas, self.lam,
-                                                     grad_scale=ce_scale, reg_grad_scale=1.0 / nworld,
+                                                     grad_scale=ce_scale, reg_grad_scale=reg_scale,
                                                      in_place=not self.keep_outputs)         # :214-216
         self._mark("loss")
         _, dfeat = native.decoder_backward(tape, dlogits, dalphas, grads=self.dec_g)         # :219
         self._mark("decoder_bwd")
-        if self.world > 1:   # decoder bucket goes out while the depth-encoder backward still runs
+        if not self.use_depth:       # base-soft / base-hard: the decoder bucket is everything there is (base_train.py:115)
+            if self.world > 1:
+                exchange_gradients(self.flat.grad, [self.dec_span], self.pg)
+        elif self.world > 1:   # decoder bucket goes out while the depth-encoder backward still runs
             exchange_gradients(self.flat.grad, [self.dec_span, self.enc_span], self.pg,
                                between=lambda: native.depth_encoder_backward(dtape, dfeat, grads=self.enc_g))
         else:
@@ -436,6 +468,13 @@ class CaptionTrainer:
         train-mode forward: the depth encoder's = optimiser steps taken, the frozen ResNet's = train-mode forwards, Q1)."""
         dev = self.device
         dec = {k: v.detach().clone() for k, v in self.dec_w.items()}
+        rgb = {k: v.detach().clone() for k, v in self.rn_w.items()}
+        for k in list(rgb):
+            if k.endswith("running_mean"):
+                rgb[k[:-len("running_mean")] + "num_batches_tracked"] = torch.tensor(self.resnet.train_forwards,
+                                                                                   dtype=torch.int64, device=dev)
+        if not self.use_depth:
+            return {"decoder": dec, "encoder": rgb}
         enc = {k: v.detach().clone() for k, v in self.enc_w.items()}
         enc.update({k: v.detach().clone() for k, v in self.enc_state.items()})
         nbt = torch.tensor(self.depth_fwd_count, dtype=torch.int64, device=dev)
@@ -446,9 +485,4 @@ class CaptionTrainer:
                 enc[f"features.{bn_idx}.{kind}"] = enc[f"bn{i}.{kind}"].clone()
             for kind in ("running_mean", "running_var", "num_batches_tracked"):
                 enc[f"features.{bn_idx}.{kind}"] = enc[f"bn{i}.{kind}"].clone()
-        rgb = {k: v.detach().clone() for k, v in self.rn_w.items()}
-        for k in list(rgb):
-            if k.endswith("running_mean"):
-                rgb[k[:-len("running_mean")] + "num_batches_tracked"] = torch.tensor(self.resnet.train_forwards,
-                                                                                   dtype=torch.int64, device=dev)
         return {"decoder": dec, "depth_encoder": enc, "encoder": rgb}

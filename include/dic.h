@@ -160,6 +160,22 @@ int dic_pack_targets(const int64_t* captions, int cap_stride, const int* dec_len
 int dic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* ---- data parallel (the reference itself is single-GPU, config.py:68): the path has ONE exchange step, a
+ *      sum all-reduce of the flat gradient buffer between dic_decoder_bwd / dic_depth_encoder_bwd and dic_adamw_step.  The
+ *      Python engine issues it through torch.distributed (backend "nccl" = RCCL); these entry points are the same exchange
+ *      for callers that bind the C ABI directly.  RCCL is resolved at run time (dlopen; an RCCL the process already holds is
+ *      reused).  One process per GPU: rank 0 obtains an id, hands the DIC_COMM_ID_BYTES bytes to the other ranks by any
+ *      means (file, socket, MPI), every rank calls dic_comm_create after hipSetDevice.  Gradients must arrive pre-scaled
+ *      (dic_caption_loss: grad_scale = this rank's share of the packed tokens, reg_grad_scale = 1 / ranks) so that the SUM is
+ *      the gradient of the global loss.  In place, enqueued on `stream`, no host synchronisation. */
+#define DIC_COMM_ID_BYTES 128
+typedef struct dic_comm dic_comm;
+int dic_comm_unique_id(void* id128);
+int dic_comm_create(const void* id128, int nranks, int rank, dic_comm** out);
+int dic_allreduce_grads(dic_comm* comm, float* flat_grad, long long count, void* stream);
+int dic_comm_ranks(const dic_comm* comm, int* nranks, int* rank);
+int dic_comm_destroy(dic_comm* comm);
+
 /* ---- dropout multiplier (nn.Dropout(p) in train mode, depth_models.py:119,197): out[i] = 0 or 1/(1-p),
  *      Philox4x32-10 counter-based stream keyed by (seed, offset). */
 int dic_dropout_mask(float* out, long long n, float p, uint64_t seed, uint64_t offset, void* stream);

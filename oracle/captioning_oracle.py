@@ -364,3 +364,41 @@ def train_step_soft(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_stat
     gd = {k: v.grad for k, v in dw.items()}
     ge = {k: v.grad for k, v in ew.items()}
     return loss.detach(), packed.detach(), alphas.detach(), gd, ge
+
+
+def train_step_base_soft(dec_w: Dict[str, Tensor], feats_rgb: Tensor, captions: Tensor, lengths: Sequence[int],
+                         drop_mult: Optional[Tensor], att_masks: Optional[Tensor] = None, report: Optional[dict] = None):
+    """One iteration of train_base_soft (Base_caption_model/base_train.py:149-167): RNNDecoderWithSoftAttention forward
+    (base_caption_models.py:105-185), CE + 0.7 x regulariser, backward; gradients for the decoder only (the optimiser holds
+    decoder.parameters(), base_train.py:115).  The base decoder is the CD_ decoder without the `features + depth_features`
+    line (depth_models.py:163 vs base_caption_models.py:132): zero depth features reproduce it exactly (x + 0 = x), which
+    is how SURVEY.md 8c defines the oracle for the un-importable base classes.  Returns (loss, packed_logits, alphas, grads)."""
+    dw = {k: v.detach().clone().requires_grad_(True) for k, v in dec_w.items()}
+    packed, _, alphas = decoder_forward(dw, feats_rgb, torch.zeros_like(feats_rgb), captions, lengths, drop_mult,
+                                        att_masks=att_masks, report=report)
+    loss = caption_loss(packed, pack_targets(captions, lengths), alphas)               # base_train.py:160-162
+    loss.backward()                                                                    # :165
+    return loss.detach(), packed.detach(), alphas.detach(), {k: v.grad for k, v in dw.items()}
+
+
+@torch.no_grad()
+def step_logits(dec_w: Dict[str, Tensor], enc_w: Dict[str, Tensor], enc_state: Dict[str, Tensor], feats_rgb: Tensor,
+                depth_map: Tensor, captions: Tensor, lengths: Sequence[int], drop_mult: Optional[Tensor]):
+    """Forward half of train_step_soft (depth_train.py:204-216) without autograd: (loss, packed_logits).  The parity tests
+    evaluate it in fp64 (weights, features, depth map and dropout multiplier as double) as the yardstick of what an fp32
+    evaluation of the step can decide."""
+    fd = depth_encoder_forward(enc_w, {k: v.clone() for k, v in enc_state.items()}, depth_map, train=True)
+    packed, _, alphas = decoder_forward(dec_w, feats_rgb, fd, captions, lengths, drop_mult)
+    return caption_loss(packed, pack_targets(captions, lengths), alphas), packed
+
+
+def rows_undecidable_by_oracle(packed32: Tensor, packed64: Tensor, factor: float = 2.0) -> Tensor:
+    """bool [N]: packed rows whose token-id argmax the fp32 ORACLE ITSELF cannot decide - its fp32 and fp64 evaluations pick
+    different tokens, or its fp32 top-2 margin is within `factor` x its own max |logit32 - logit64| on that row.  Defined by the
+    oracle's two precisions only: nothing of the implementation under test enters.  Everywhere else a
+    correct fp32 implementation must reproduce the oracle's argmax exactly."""
+    p32, p64 = packed32.double(), packed64.double()
+    top2 = p32.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    own_err = (p32 - p64).abs().max(dim=1).values
+    return (p32.argmax(1) != p64.argmax(1)) | (margin <= factor * own_err)

@@ -32,6 +32,7 @@ def test_bench_gpus2_self_launch_over_gloo_on_one_gpu(lib):
     assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["global_batch"] == 16
     assert d["config"]["batch_per_gpu"] == 8 and d["scaling"] == "weak" and "all-reduce" in d["config"]["collective"]
     assert d["value"] > 0 and d["loss"] == d["loss"]            # finite
+    assert d["config"]["collective_ranks"] == 2 and "ok" in d["config"]["collective_self_check"]
 
 
 @pytest.mark.parametrize("full_size", [False, True])
@@ -84,3 +85,34 @@ def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path, full_size, monke
         assert abs(ranks[rank]["loss"] - losses[rank]) <= 1e-5, (rank, ranks[rank]["loss"], losses[rank])
     err = float((tr.flat.data.cpu() - ranks[0]["params"]).abs().max())
     assert err <= 1e-5, f"2-rank parameters differ from the 1-rank emulation by {err:.3e}"
+
+
+def test_rccl_entry_points_of_the_c_abi_single_rank(lib):
+    """dic_comm_unique_id / dic_comm_create / dic_allreduce_grads / dic_comm_destroy (include/dic.h, "data parallel"): the
+    gradient exchange for callers that bind the C ABI without torch.distributed.  A one-GPU box admits one RCCL rank per
+    device, so this checks what can be checked here: RCCL resolves at run time (the copy this process already holds, i.e.
+    PyTorch's), a 1-rank communicator comes up on cuda:0, a sum all-reduce of a gradient-sized flat buffer (6.5 M floats) on
+    the caller's stream returns the buffer bit for bit, errors come back as codes with a message."""
+    import ctypes as C
+    from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda:0")
+    ident = (C.c_char * 128)()
+    check(lib.dic_comm_unique_id(ident), "dic_comm_unique_id")
+    assert any(b != 0 for b in bytes(ident))
+    comm = C.c_void_p()
+    check(lib.dic_comm_create(ident, 1, 0, C.byref(comm)), "dic_comm_create")
+    try:
+        n, r = C.c_int(-1), C.c_int(-1)
+        check(lib.dic_comm_ranks(comm, C.byref(n), C.byref(r)), "dic_comm_ranks")
+        assert (n.value, r.value) == (1, 0)
+        g = torch.randn(6_471_104, device="cuda:0")
+        ref = g.clone()
+        check(lib.dic_allreduce_grads(comm, ptr(g), C.c_longlong(g.numel()), stream_ptr()), "dic_allreduce_grads")
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref)
+        assert lib.dic_allreduce_grads(comm, None, C.c_longlong(4), stream_ptr()) != 0
+        assert b"bad arguments" in lib.dic_last_error()
+    finally:
+        check(lib.dic_comm_destroy(comm), "dic_comm_destroy")
+    assert lib.dic_comm_create(ident, 2, 5, C.byref(comm)) != 0          # rank outside [0, nranks)

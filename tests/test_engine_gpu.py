@@ -216,6 +216,48 @@ def test_two_forwards_in_flight_equal_sequential_forwards(lib):
         tr.prefetch_features(batches[0]); tr.prefetch_features(batches[1]); tr.prefetch_features(batches[2])
 
 
+def test_prefetch_order_deviation_is_flushed_not_silently_stuck(lib):
+    """A caller that leaves the announced batch order once (here: batch 2 is skipped, batch 3 arrives while the forwards of 2
+    and 3 are in flight; later a batch that was never announced) must not wedge the prefetch queue: the forwards
+    of unconsumed batches are discarded - their BatchNorm deltas never applied, as if they had not run - with a warning and a
+    counter, the next steps prefetch again, and the running statistics equal those of the CONSUMED batches run one at a time
+    in consumption order."""
+    B, size = 2, 64
+    batches = [syn.rgb_images(B, seed=280 + i, size=size).to(DEV) for i in range(7)]
+    tr = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode="bf16x3")
+    ref = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode="bf16x3")
+    consumed = []
+
+    def take(i):
+        f = tr._take_prefetched(batches[i])
+        if f is None:                                           # not in flight: the eager path of train_step
+            f = tr._resnet_eager(batches[i], True, False)
+        consumed.append(i)
+        return f.clone()                                        # (the step's feature buffer is reused by the next take)
+
+    tr.prefetch_features(batches[0]); tr.prefetch_features(batches[1])
+    take(0); tr.prefetch_features(batches[2])
+    take(1); tr.prefetch_features(batches[3])                   # in flight: 2, 3
+    with pytest.warns(RuntimeWarning, match="discarded"):
+        f3 = take(3)                                            # batch 2 skipped: its forward is dropped, batch 3 is taken
+    assert tr.prefetch_dropped == 1 and len(tr.queue) == 0
+    tr.prefetch_features(batches[4]); tr.prefetch_features(batches[5])      # prefetching resumes
+    with pytest.warns(RuntimeWarning, match="discarded"):
+        f6 = take(6)                                            # never announced: both pending forwards dropped, eager forward
+    assert tr.prefetch_dropped == 3 and len(tr.queue) == 0
+    tr.prefetch_features(batches[4])
+    f4 = take(4)
+    torch.cuda.synchronize()
+    feats = {}
+    for i in consumed:
+        feats[i] = ref.resnet.forward(batches[i], train_bn=True).clone()
+    torch.cuda.synchronize()
+    assert consumed == [0, 1, 3, 6, 4]
+    assert torch.equal(f3, feats[3]) and torch.equal(f6, feats[6]) and torch.equal(f4, feats[4])
+    for k in tr.rn_stat_keys:
+        _close(k, tr.rn_w[k], ref.rn_w[k], 1e-6, 1e-9)
+
+
 @pytest.mark.parametrize("forward_kernels", ["policy", "gather"])
 def test_overlapped_step_is_bit_reproducible_at_bench_shape(lib, forward_kernels):
     """Bench shape (64 x 224 x 224, vocabulary 10000, T = 20): the gradient computation of a step is repeated on fixed

@@ -21,9 +21,11 @@ B. Everything after the RGB encoder at the north_star bars and tighter: the orac
    zero true gradient (softmax shift invariance; a bias in front of train-mode BatchNorm cancels) - both sides hold
    rounding noise only, which must stay 100x below the sibling weight gradient's scale.  Nothing else is exempted.
 C. End to end against the oracle run entirely on its own (own ResNet features, own selections): loss |d| <= 1e-4; argmax
-   identical on every packed row whose oracle top-2 logit margin exceeds twice that row's measured max |d logit| (a row inside
-   that band cannot be decided by ANY fp32 evaluation: the oracle itself is that far from fp64); the number of rows in
-   the band and the number of mismatches are printed."""
+   identical on every packed row that the ORACLE can decide.  Undecidable rows are defined by the oracle alone
+   (orc.rows_undecidable_by_oracle): the same step evaluated in fp64 on the fp64 ResNet features picks another token, or
+   the fp32 oracle's top-2 margin is within twice its own |logit32 - logit64| on that row.  Nothing measured on the HIP path
+   enters the exemption (round 2 scaled it with the HIP path's own error).  At most 2 % of the rows may be undecidable;
+   their number and the number of mismatches inside / outside are printed."""
 import copy
 
 import pytest
@@ -69,6 +71,10 @@ def _inputs(B):
     o["feats64"] = orc.resnet152_features({k: v.double() for k, v in o["rn"].items()}, o["imgs"].double(), train_bn=True)
     o["own"] = orc.train_step_soft(o["dec"], o["enc"], copy.deepcopy(o["st"]), o["feats"], o["depth"], o["caps"], o["lens"],
                                    o["drop"])
+    d64 = lambda d: {k: v.double() for k, v in d.items()}                                    # noqa: E731
+    o["own64"] = orc.step_logits(d64(o["dec"]), d64(o["enc"]), d64(o["st"]), o["feats64"], o["depth"].double(), o["caps"],
+                                 o["lens"], o["drop"].double())
+    o["undecidable"] = orc.rows_undecidable_by_oracle(o["own"][1], o["own64"][1])
     _INPUTS[B] = o
     return o
 
@@ -141,14 +147,14 @@ def test_full_size_step_vs_oracle(lib, B, conv_mode, compact):
     l_own, packed_own = float(o["own"][0]), o["own"][1]
     assert abs(loss - l_own) <= 1e-4, f"loss {loss:.6f} vs oracle {l_own:.6f}"
     e_log, _ = _err(logits, packed_own)
-    top2 = packed_own.topk(2, dim=1).values
-    margin = top2[:, 0] - top2[:, 1]
-    decidable = margin > 2.0 * (logits.cpu() - packed_own).abs().max(dim=1).values      # per row: 2 x that row's max |d logit|
+    undec = o["undecidable"]                                   # from the oracle's fp32 and fp64 evaluations alone
     mism = logits.argmax(1).cpu() != packed_own.argmax(1)
-    print(f"end to end: loss d {abs(loss - l_own):.2e}, max |d logit| {e_log:.2e}, rows inside the rounding band "
-          f"{int((~decidable).sum())} of {margin.numel()}, argmax mismatches {int(mism.sum())}")
-    assert not bool((mism & decidable).any()), "argmax differs on a row whose margin is outside the rounding band"
-    assert int((~decidable).sum()) <= margin.numel() // 20, "rounding band too wide for the comparison to mean anything"
+    print(f"end to end: loss d {abs(loss - l_own):.2e}, max |d logit| {e_log:.2e}, rows_undecidable_by_oracle "
+          f"{int(undec.sum())} of {undec.numel()} (oracle fp32 vs fp64 loss d {abs(l_own - float(o['own64'][0])):.2e}), "
+          f"argmax mismatches {int(mism.sum())} ({int((mism & undec).sum())} on undecidable rows)")
+    assert not bool((mism & ~undec).any()), (f"argmax differs on {int((mism & ~undec).sum())} row(s) that the oracle's own "
+                                             "fp32 / fp64 evaluations decide")
+    assert int(undec.sum()) <= undec.numel() // 50, "more than 2 % of the rows are undecidable by the oracle itself"
     del tr
     torch.cuda.empty_cache()
 
@@ -202,3 +208,74 @@ def test_full_size_hard_attention_step_vs_oracle(lib):
     own = orc.train_step_soft(o["dec"], o["enc"], copy.deepcopy(o["st"]), o["feats"], o["depth"], o["caps"], o["lens"], o["drop"],
                               hard_u=u, temp=temp)
     assert abs(loss - float(own[0])) <= 1e-4, (loss, float(own[0]))
+
+
+def test_config1_base_soft_8_images_step_vs_oracle(lib):
+    """BASELINE config 1 (`base_main.py soft coco` on 8 images; reference base_main.py:23-27 -> base_train.py:24-234): one
+    training step of the base-soft captioner - full ResNet-152 in train() mode (batch-statistics BatchNorm over the 8 images) ->
+    RNNDecoderWithSoftAttention (ragged caption lengths, explicit dropout mask) -> CE + 0.7 x regulariser -> AdamW over the
+    decoder only - through the fused engine with the depth branch off (feat_depth = NULL), in both decoder layouts.
+      same-features: the oracle on the HIP path's ResNet features: loss 1e-5, logits / alphas 1e-4, argmax identical on every
+        row, all 17 decoder gradients 1e-3 of scale (full_att.bias: exactly-zero true gradient, Q10), post-AdamW weights;
+      end to end: the oracle on its own ResNet features: loss 1e-4 and identical argmax on every row the oracle's own fp32 and
+        fp64 evaluations decide alike (8 images give BatchNorm very few samples: the printed counts say how many rows that is)."""
+    B, V = 8, 10000
+    lengths = [21, 19, 17, 14, 12, 12, 9, 6]
+    dec = syn.decoder_weights(V, seed=123)
+    rn = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(B, seed=321)
+    caps, lens = syn.captions_ragged(lengths, V, seed=321)
+    tmax = max(lens) - 1
+    drop = syn.dropout_multiplier(B, tmax, 0.5, seed=321)
+    feats_own = orc.resnet152_features(copy.deepcopy(rn), imgs, train_bn=True)
+    own = orc.train_step_base_soft(dec, feats_own, caps, lens, drop)
+    d64 = lambda d: {k: v.double() for k, v in d.items()}                                    # noqa: E731
+    feats64 = orc.resnet152_features(d64(rn), imgs.double(), train_bn=True)
+    with torch.no_grad():
+        p64, _, _ = orc.decoder_forward(d64(dec), feats64, torch.zeros_like(feats64), caps, lens, drop.double())
+    undec = orc.rows_undecidable_by_oracle(own[1], p64)
+    for compact in (True, False):
+        tr = CaptionTrainer(V, device=DEV, seed=123, decoder_init=dec, resnet_init=copy.deepcopy(rn), conv_mode="bf16x3",
+                            use_depth=False)
+        tr.compact_ok = compact
+        tr.keep_outputs = True
+        w0 = {k: v.clone() for k, v in tr.dec_w.items()}
+        loss = tr.train_step(imgs.to(DEV), None, caps.to(DEV), lens, drop_mult=drop.to(DEV))
+        torch.cuda.synchronize()
+        loss = float(loss.item())
+        feats = tr.last["features"].cpu()
+        assert feats.shape[1] == (49 if compact else 196) and tr.last["depth_features"] is None
+        assert set(tr.state_dicts()) == {"decoder", "encoder"}            # two checkpoints: base_train.py:227-234
+        # ---- same features ----
+        f196 = _cells196(feats, B)
+        l_ref, packed_ref, alphas_ref, gd = orc.train_step_base_soft(dec, f196, caps, lens, drop)
+        logits = tr.last["logits"]
+        assert abs(loss - float(l_ref)) <= 1e-5, (loss, float(l_ref))
+        e, s = _err(logits, packed_ref)
+        assert e <= 1e-4 * s, f"logits {e:.3e} vs {s:.3e}"
+        assert torch.equal(logits.argmax(1).cpu(), packed_ref.argmax(1)), "token-id argmax must be identical on every row"
+        e, s = _err(tr.last["alphas"], alphas_ref)
+        assert e <= 1e-4 * s, f"alphas {e:.3e} vs {s:.3e}"
+        m = {k: torch.zeros_like(v) for k, v in dec.items()}
+        v2 = {k: torch.zeros_like(v) for k, v in dec.items()}
+        post = {k: v.clone() for k, v in dec.items()}
+        orc.adamw_step(post, gd, m, v2, step=1)
+        for k in dec:
+            e, s = _err(tr.dec_g[k], gd[k])
+            if k == "attention.full_att.bias":                            # exactly-zero true gradient (Q10): noise only, and Adam
+                assert e <= 1e-2 * float(gd["attention.full_att.weight"].abs().max())      # normalises noise to +-lr
+                continue
+            assert e <= 1e-3 * s, f"grad {k}: {e:.3e} vs scale {s:.3e}"
+            # AdamW's first step moves every element by ~lr * sign(g): compare where the oracle's gradient is not rounding noise
+            big = gd[k].abs() > 1e-3 * gd[k].abs().max()
+            d = (tr.dec_w[k].cpu() - post[k]).abs()[big]
+            assert d.numel() == 0 or float(d.max()) <= 2e-5, f"post-AdamW {k}: {float(d.max()):.3e}"
+            assert not torch.equal(tr.dec_w[k], w0[k]), k
+        # ---- end to end ----
+        assert abs(loss - float(own[0])) <= 1e-4, (loss, float(own[0]))
+        mism = logits.argmax(1).cpu() != own[1].argmax(1)
+        print(f"\nconfig 1 ({49 if compact else 196} cells): loss d {abs(loss - float(own[0])):.2e}, rows_undecidable_by_oracle "
+              f"{int(undec.sum())} of {undec.numel()}, argmax mismatches {int(mism.sum())} ({int((mism & undec).sum())} undecidable)")
+        assert not bool((mism & ~undec).any())
+        del tr
+        torch.cuda.empty_cache()

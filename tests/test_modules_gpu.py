@@ -104,6 +104,42 @@ def test_attention_modules_are_differentiable(lib, hard):
             _close("grad " + k, p.grad, wr["attention." + k].grad, 1e-3)
 
 
+def test_base_main_cli_smoke(lib, tmp_path, monkeypatch):
+    """BASELINE config 1's plumbing: `base_main {soft,hard} synthetic` (reference: base_main.py:14-43 -> train_base_soft /
+    train_base_hard, base_train.py:24,248) for a tiny configuration - loss CSVs and the TWO best-validation checkpoints
+    (encoder, decoder; there is no depth encoder) with the reference's file names, loadable with strict=True; base-hard writes
+    into save_directory_soft like the reference (base_train.py:253)."""
+    from depth_image_captioning_pub_amd import base_main
+    from depth_image_captioning_pub_amd.Captioning_models import config as cfg_mod
+    from depth_image_captioning_pub_amd.Captioning_models.Base_caption_model import base_train
+    from depth_image_captioning_pub_amd.Captioning_models.Base_caption_model.base_caption_models import (
+        RNNDecoderWithHardAttention, RNNDecoderWithSoftAttention)
+
+    class Tiny(cfg_mod.ConfigTrain):
+        def __init__(self):
+            super().__init__()
+            self.batch_size, self.num_epochs, self.vocab_size, self.seq_len, self.iters_per_epoch = 2, 1, 120, 6, 2
+            self.save_directory_soft = str(tmp_path / "base_soft")
+            self.save_directory_hard = str(tmp_path / "base_hard")
+    monkeypatch.setattr(base_train, "ConfigTrain", Tiny)
+    monkeypatch.setattr(base_main, "EXP_TIME", 1)
+    assert base_main.main(["base_main"]) == 1 and base_main.main(["base_main", "soft", "imagenet"]) == 1
+    d = tmp_path / "base_soft"
+    for kind in ("soft", "hard"):
+        tag = f"base_{kind}"
+        assert base_main.main(["base_main", kind, "synthetic"]) == 0
+        tl = float((d / f"{tag}_train_loss_synthetic0.csv").read_text().strip().splitlines()[0].split(",")[1])
+        vl = float((d / f"{tag}_val_loss_synthetic0.csv").read_text().strip().splitlines()[0].split(",")[1])
+        assert np.isfinite(tl) and np.isfinite(vl) and vl != tl
+        enc = CNNEncoder_Atten(14)
+        dec = (RNNDecoderWithHardAttention(128, 128, 2048, 128, 120, DEV, 0.5) if kind == "hard"
+               else RNNDecoderWithSoftAttention(128, 128, 2048, 128, 120, 0.5))
+        enc.load_state_dict(torch.load(d / f"{tag}_encoder_best_synthetic0.pth", weights_only=True), strict=True)
+        dec.load_state_dict(torch.load(d / f"{tag}_decoder_best_synthetic0.pth", weights_only=True), strict=True)
+        assert not (d / f"{tag}_D_encoder_best_synthetic0.pth").exists()
+    assert not (tmp_path / "base_hard").exists()
+
+
 def test_depth_main_cli_smoke(lib, tmp_path, monkeypatch):
     """The drop-in CLI of north_star: `depth_main {soft,hard} cnn synthetic` (reference: depth_main.py:14-35 ->
     train_Cdepth_soft/_hard, depth_train.py:27,338) for a tiny configuration - 1 epoch x 2 iterations, validation
