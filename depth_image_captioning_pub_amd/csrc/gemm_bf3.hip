@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 // (scripts/bench_bf3_pipe_ablate.py) - a global_load_lds that cannot issue (address arithmetic, M0 set-up, a full
 // vector-memory queue) blocks the MFMAs queued behind it in the same wave.  A producer wave that blocks costs nothing.
 // Two waves per SIMD, so the kernel has to fit 256 registers; the stores of a seam and the DMA no longer share a vmcnt.
-template <int AK, int ABL = 0, int NST = 3>      // ABL (measurement only): 1 = the producer waves issue nothing inside the loop; NST: ring stages
+template <int AK, int ABL = 0, int NST = 3>      // ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
 __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
@@ -381,8 +381,8 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
     }
     auto prefetch = [&](unsigned short* stage) {
-      la.template issue<DIC_WS_A_AUX>(pkt * BK3, stage);
-      lbld.issue(pkt * BK3, stage + AOPER);
+      la.template issue<DIC_WS_A_AUX>((ABL >= 3 ? 0 : pkt) * BK3, stage);
+      lbld.issue((ABL >= 4 ? 0 : pkt) * BK3, stage + AOPER);
       if (++pkt == nkt) {
         pkt = 0; ++pj;
         if (pj < ntl) {
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
-      if (ABL == 0 && g + NST < total) prefetch(smem + st * STAGE);
+      if (ABL != 1 && g + NST < total) prefetch(smem + st * STAGE);
       st = st == NST - 1 ? 0 : st + 1;
     }
     return;
@@ -823,7 +823,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
   if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
   if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
-  if (code >= 50 && code <= 53) { g_bf3_ablate = code - 50; return 0; }
+  if (code >= 50 && code <= 55) { g_bf3_ablate = code - 50; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
   if (code == 77) { g_bf3_ws = 0; return 0; }
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }
   if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
@@ -940,6 +940,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
     if (!halo && g_bf3_ws && g_bf3_ablate == 2 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 2>), dim3(grid), dim3(512), 0, st, p);
     else if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 1>), dim3(grid), dim3(512), 0, st, p);
+    else if (!halo && g_bf3_ws && g_bf3_ablate == 4 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 3>), dim3(grid), dim3(512), 0, st, p);
+    else if (!halo && g_bf3_ws && g_bf3_ablate == 5 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 4>), dim3(grid), dim3(512), 0, st, p);
     else if (!halo && g_bf3_ws) { if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
                                   else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p); }
     else if (halo && g_bf3_ablate == 1) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<1>, dim3(grid), dim3(512), 0, st, p);
