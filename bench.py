@@ -314,8 +314,10 @@ def main():
                     help="separate workload (never mixed into the headline): forward of the frozen DPT-Hybrid depth "
                          "front-end of BASELINE config 5 at 384x384 + standardise + resize to 224 (depth_train.py:185-190)")
     ap.add_argument("--dpt-batch", type=int, default=8)
-    ap.add_argument("--prefetch-depth", type=int, default=2, choices=[1, 2, 3],
+    ap.add_argument("--prefetch-depth", type=int, default=2, choices=range(1, 13),
                     help="frozen-ResNet forwards of upcoming batches in flight on side streams (1 = round-1 behaviour)")
+    ap.add_argument("--persist-grid", type=int, default=0,
+                    help="workgroups per persistent convolution launch (dic_conv_persistent_grid; 0 = library default)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=4)
     args = ap.parse_args()
@@ -367,10 +369,13 @@ def main():
     if os.environ.get("DIC_DEBUG_SWITCHES"):          # development only: comma-separated dic_debug_force_staged_gemm codes
         for code in os.environ["DIC_DEBUG_SWITCHES"].split(","):
             _lib.check(_lib.load().dic_debug_force_staged_gemm(int(code)), f"debug switch {code}")
+    if args.persist_grid:
+        _lib.check(_lib.load().dic_conv_persistent_grid(args.persist_grid), "dic_conv_persistent_grid")
     if args.dpt:
         return bench_dpt(args, dev, world, rank)
     B = args.batch
     trainer = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=args.conv_mode)
+    trainer.prefetch_depth = args.prefetch_depth
     trainer_numel = trainer.flat.total
     if args.reference_cells:
         trainer.compact_ok = False

@@ -76,6 +76,10 @@ int dic_debug_conv_bf3(const uint16_t* const x_planes[3], int B, int H, int W, i
   ConvDesc d{B, H, W, C, CO, k, k, stride, pad, 0};
   return conv_fwd_bf3(x_planes, d, w_planes, y, bn_partial, mtiles_out, tail_ws, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
+int dic_conv_persistent_grid(int max_workgroups) {
+  DIC_REQUIRE(gemm_bf3_set_persist_grid(max_workgroups) == 0, "dic_conv_persistent_grid: 1 <= max_workgroups <= 1024");
+  return DIC_OK;
+}
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
   DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");

@@ -75,6 +75,9 @@ struct GemmParams {
   float* tail_ws;
   int ablate;           // debug/benchmark only: 1 no global traffic in the loop, 2 also no LDS reads, 3 LDS stores but no global loads
   int raw_partials;     // split-K: leave the [splitk][M][N] partial slabs in ws, skip the reduce launch
+  // tail fix-up of the 128x128 persistent kernels (gemm_bf3.hip): tail index = 4 * (remainder tile - tail128_first) + quadrant,
+  // the 64x64 tile it finishes = quadrant (q >> 1, q & 1) of 128x128 tile tail128_first + index / 4 on a grid tail128_ntiles wide
+  int tail128_first, tail128_ntiles;
 };
 
 // host side (gemm.hip)
@@ -89,6 +92,7 @@ GemmOperand op_gather(const float* x, const ConvGeom& g);
 GemmOperand op_im2col_colk(const float* x, const ConvGeom& g);
 GemmOperand op_gather_colk(const float* x, const ConvGeom& g);
 void gemm_force_v1(int on);
+int gemm_bf3_set_persist_grid(int workgroups);
 int gemm_bf3_force_tile(int code);      // 0 = accepted, -1 = unknown code in this build
 int gemm_launch_tail_fixup(const GemmParams& p, int tail_tiles, hipStream_t st);
 

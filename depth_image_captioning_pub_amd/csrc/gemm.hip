@@ -458,8 +458,15 @@ template <int NS>      // NS = slice loads issued per thread (2/4/8/16 >= tail_s
 __device__ __forceinline__ void tail_fixup_tile(const GemmParams& p, const int tail_index, float4 (*sred)[64][16],
                                                 float4 (*sred2)[8][16]) {
   constexpr int BM = 64, BN = 64;
-  const int t = p.tail_first_tile + tail_index;
-  const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+  int tm, tn;
+  if (p.tail128_ntiles > 0) {     // a quadrant of a 128x128 remainder tile (persistent split-bf16 kernels)
+    const int t128 = p.tail128_first + (tail_index >> 2), q = tail_index & 3;
+    tm = 2 * (t128 / p.tail128_ntiles) + (q >> 1);
+    tn = 2 * (t128 % p.tail128_ntiles) + (q & 1);
+  } else {
+    const int t = p.tail_first_tile + tail_index;
+    tm = t / p.ntiles; tn = t - tm * p.ntiles;
+  }
   const int c4 = threadIdx.x & 15, row = threadIdx.x >> 4;
   const float* base = p.tail_ws + (long long)tail_index * p.tail_split * BM * BN + row * BN + c4 * 4;
   float4 x[NS];

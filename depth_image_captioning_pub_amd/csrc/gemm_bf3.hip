@@ -367,26 +367,42 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = (p.K + BK3 - 1) / BK3;
   const int T = p.mtiles * p.ntiles, G = gridDim.x;
-  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
-  const int total = ntl * nkt;
+  // Work list of this workgroup: its whole tiles xcd_remap(blockIdx + j*G, F), j < ntl, then - remainder-round K split,
+  // tail_split > 1 - at most ONE piece: K tiles [pk0, pk0 + npk) of remainder tile F + blockIdx / tail_split.  The T - F
+  // remainder tiles (less than one round of the grid) are cut into tail_split K slices so that every CU gets a share of the
+  // last round; a piece leaves its raw accumulators in tail_ws (one [64][64] slab per consumer wave = per 64x64 quadrant)
+  // and tail_fixup_kernel (gemm.hip, 128x128 mode) sums the slices in K order, stores, and writes the BatchNorm partials.
+  const bool split = p.tail_split > 1;
+  const int F = split ? p.tail_first_tile : T;
+  const int ntl = (F - (int)blockIdx.x + G - 1) / G;
+  const int per = split ? (nkt + p.tail_split - 1) / p.tail_split : 0;
+  const bool has_piece = split && (int)blockIdx.x < (T - F) * p.tail_split;
+  const int piece_tile = has_piece ? F + (int)blockIdx.x / p.tail_split : 0;
+  const int pk0 = has_piece ? ((int)blockIdx.x % p.tail_split) * per : 0;
+  const int npk = has_piece ? min(nkt, pk0 + per) - pk0 : 0;
+  const int nwork = ntl + (has_piece ? 1 : 0);
+  const int total = ntl * nkt + npk;
+  if (total == 0) return;
 
   if (wave >= 4) {
     // ---------------- producer waves: slot g of the stream goes to ring stage g % NST
     Bf3Loader<AK, BM> la;
     Bf3Loader<OPK_ROWK, BN> lbld;
-    int pj = 0, pkt = 0;
+    int pj = 0, pkt = 0, k0cur = ntl > 0 ? 0 : pk0, nkcur = ntl > 0 ? nkt : npk;
     {
-      const int t = xcd_remap(blockIdx.x, T);
+      const int t = ntl > 0 ? xcd_remap(blockIdx.x, F) : piece_tile;
       la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
       lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
     }
     auto prefetch = [&](unsigned short* stage) {
-      la.template issue<DIC_WS_A_AUX>((ABL >= 3 ? 0 : pkt) * BK3, stage);
-      lbld.issue((ABL >= 4 ? 0 : pkt) * BK3, stage + AOPER);
-      if (++pkt == nkt) {
+      la.template issue<DIC_WS_A_AUX>((ABL >= 3 ? 0 : k0cur + pkt) * BK3, stage);
+      lbld.issue((ABL >= 4 ? 0 : k0cur + pkt) * BK3, stage + AOPER);
+      if (++pkt == nkcur) {
         pkt = 0; ++pj;
-        if (pj < ntl) {
-          const int t = xcd_remap(blockIdx.x + pj * G, T);
+        if (pj < nwork) {
+          const bool whole = pj < ntl;
+          const int t = whole ? xcd_remap(blockIdx.x + pj * G, F) : piece_tile;
+          k0cur = whole ? 0 : pk0; nkcur = whole ? nkt : npk;
           la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
           lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
         }
@@ -440,8 +456,9 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
   DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
   int g = 0, st = 0;
-  for (int j = 0; j < ntl; ++j) {
-    for (int kt = 0; kt < nkt; ++kt, ++g) {
+  for (int j = 0; j < nwork; ++j) {
+    const int nkj = j < ntl ? nkt : npk;
+    for (int kt = 0; kt < nkj; ++kt, ++g) {
       const int stn = st == NST - 1 ? 0 : st + 1;
       const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
       DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
@@ -460,18 +477,24 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       __builtin_amdgcn_sched_barrier(0);
       st = stn;
     }
-    // ---- seam: store the tile
-    const int t = xcd_remap(blockIdx.x + j * G, T);
+    // ---- seam: store the tile.  The piece of a remainder tile (j == ntl) goes through the same stores with the output
+    // matrix replaced by this wave's [64][64] slab of raw partial sums in tail_ws (quadrant-major, then slice): no bias /
+    // activation / statistics - tail_fixup_kernel sums the slices and does the rest
+    const bool piece = j >= ntl;
+    const int t = piece ? piece_tile : xcd_remap(blockIdx.x + j * G, F);
     const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
-    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-    const bool plain = !p.ep.bias && p.ep.act == ACT_NONE && !p.ep.accumulate;
-    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    const bool full = piece || ((tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N);
+    const bool plain = piece || (!p.ep.bias && p.ep.act == ACT_NONE && !p.ep.accumulate);
+    const int n0 = piece ? (lane & 31) : tn * BN + wn * 64 + (lane & 31), m0 = piece ? 4 * h : tm * BM + wm * 64 + 4 * h;
+    float* const Cb = piece ? p.tail_ws + ((long long)(((int)blockIdx.x / p.tail_split) * 4 + wave) * p.tail_split + (int)blockIdx.x % p.tail_split) * (64 * 64)
+                            : p.ep.C;
+    const long long ldc = piece ? 64 : p.ep.ldc;
     float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        float* col = Cb + (long long)(m0 + i * 32) * ldc + n0 + jj * 32;
         if (!plain) {      // bias / activation / accumulate (finalize_store's order): the stored value replaces the accumulator
           const int n = n0 + jj * 32;
           const float bcol = (p.ep.bias && n < p.N) ? p.ep.bias[n] : 0.f;
@@ -479,7 +502,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 #pragma unroll
           for (int r = 0; r < 16; ++r) {        // C += result: all 16 old values in flight before the first store
             const bool in = m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n < p.N;
-            old[r] = (p.ep.accumulate && in) ? col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] : 0.f;
+            old[r] = (p.ep.accumulate && in) ? col[(long long)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -489,17 +512,17 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
             else if (p.ep.act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
             const bool in = m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n < p.N;
             v = in ? v + old[r] : 0.f;          // outside the matrix: nothing stored, nothing in the statistics
-            if (in) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = v;
+            if (in) col[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = v;
             acc[i][jj][r] = v;
           }
         } else if (full) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][jj][r];
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
-              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+              col[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][jj][r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
@@ -507,7 +530,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
           acc[i][jj][r] = 0.f;
         }
       }
-    if (p.ep.stats) {
+    if (p.ep.stats && !piece) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
@@ -552,12 +575,26 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.A.g.H, W = p.A.g.W, C = p.A.g.C, ohw = H * W, nimg = p.M / ohw;
-  const int NC = C / BK3, per_tile = NC * 9;
+  const int NC = C / BK3;
   const int T = p.mtiles * p.ntiles, G = gridDim.x;
-  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
-  const int total = ntl * per_tile, nchunks = ntl * NC;
+  // Work list as in gemm_bf3_persist_ws_kernel: whole tiles, then (remainder-round K split, tail_split > 1) at most one piece =
+  // the channel chunks [pc0, pc0 + npc) of remainder tile F + blockIdx / tail_split, all nine taps each.
+  const bool split = p.tail_split > 1;
+  const int F = split ? p.tail_first_tile : T;
+  const int ntl = (F - (int)blockIdx.x + G - 1) / G;
+  const int perc = split ? (NC + p.tail_split - 1) / p.tail_split : 0;
+  const bool has_piece = split && (int)blockIdx.x < (T - F) * p.tail_split;
+  const int piece_tile = has_piece ? F + (int)blockIdx.x / p.tail_split : 0;
+  const int pc0 = has_piece ? ((int)blockIdx.x % p.tail_split) * perc : 0;
+  const int npc = has_piece ? min(NC, pc0 + perc) - pc0 : 0;
+  const int nwork = ntl + (has_piece ? 1 : 0);
+  const int nchunks = ntl * NC + npc, total = nchunks * 9;
+  if (total == 0) return;
 
-  auto tile_of = [&](int j, int& tm, int& tn) { const int t = xcd_remap(blockIdx.x + j * G, T); tm = t / p.ntiles; tn = t - tm * p.ntiles; };
+  auto tile_of = [&](int j, int& tm, int& tn) {
+    const int t = j < ntl ? xcd_remap(blockIdx.x + j * G, F) : piece_tile;
+    tm = t / p.ntiles; tn = t - tm * p.ntiles;
+  };
   auto row_lo = [&](int tm) {                     // first padded row of the tile's halo
     const int m0 = tm * BM, b0 = m0 / ohw, oy0 = (m0 - b0 * ohw) / W;
     return b0 * (H + 1) + oy0;
@@ -589,9 +626,10 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
         if (r < RMAX && rr != 0 && b < nimg && (unsigned)ix < (unsigned)W) hok |= 1u << t;
       }
     };
-    auto issue_halo = [&](int n) {
-      const int cc = n % NC;
-      if (cc == 0) setup_halo(n / NC);
+    auto issue_halo = [&](int n) {                          // n-th chunk of the work list
+      const bool in_piece = n >= ntl * NC;
+      const int cc = in_piece ? pc0 + (n - ntl * NC) : n % NC;
+      if (in_piece ? n == ntl * NC : cc == 0) setup_halo(in_piece ? ntl : n / NC);
       unsigned short* buf = smem + (n & 1) * HBUF;
 #pragma unroll
       for (int t = 0; t < NHALO; ++t) {
@@ -604,16 +642,17 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
     };
     // weight slot s = (tile, chunk, tap) in that order, K offset tap*C + 32*chunk
     Bf3Loader<OPK_ROWK, BN> lbld;
-    int pj = 0, pcc = 0, ptap = 0, pst = 0;
+    int pj = 0, pcc = ntl > 0 ? 0 : pc0, pend = ntl > 0 ? NC : pc0 + npc, ptap = 0, pst = 0;
     { int tm, tn; tile_of(0, tm, tn); lbld.init(p.B, tn * BN, p.N, p.K); }
     auto issue_b = [&]() {
       lbld.issue(ptap * C + pcc * BK3, bring + pst * BSTAGE);
       pst = pst == NSTB - 1 ? 0 : pst + 1;
       if (++ptap == 9) {
         ptap = 0;
-        if (++pcc == NC) {
-          pcc = 0; ++pj;
-          if (pj < ntl) { int tm, tn; tile_of(pj, tm, tn); lbld.init(p.B, tn * BN, p.N, p.K); }
+        if (++pcc == pend) {
+          ++pj;
+          pcc = pj < ntl ? 0 : pc0; pend = pj < ntl ? NC : pc0 + npc;
+          if (pj < nwork) { int tm, tn; tile_of(pj, tm, tn); lbld.init(p.B, tn * BN, p.N, p.K); }
         }
       }
     };
@@ -626,8 +665,8 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
     __builtin_amdgcn_s_barrier();
     int g = 0, n = 0;
     bool halo_prev = false;                        // the previous slot issued a halo chunk (10 instructions before its weights)
-    for (int j = 0; j < ntl; ++j)
-      for (int cc = 0; cc < NC; ++cc, ++n)
+    for (int j = 0; j < nwork; ++j)
+      for (int cc = 0; cc < (j < ntl ? NC : npc); ++cc, ++n)
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap, ++g) {
           // weight tile g+1 (and, before tap 0 of a chunk, that chunk's halo - older still) must have landed; younger, in issue
@@ -689,8 +728,9 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
   DIC_HALO_READ_A(0, 0, qb, 0) DIC_HALO_READ_B(0, 0)
 
   int g = 0, st = 0, n = 0;                        // slot, its weight stage, its (global) chunk
-  for (int j = 0; j < ntl; ++j) {
-    for (int cc = 0; cc < NC; ++cc, ++n) {
+  for (int j = 0; j < nwork; ++j) {
+    const int ncj = j < ntl ? NC : npc;            // chunks of this work item (the piece: a slice of the channels)
+    for (int cc = 0; cc < ncj; ++cc, ++n) {
       const int hb = n & 1;
 #pragma unroll 1
       for (int tap = 0; tap < 9; ++tap, ++g) {
@@ -711,7 +751,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
           if (tap < 8) {
             const int t1 = tap + 1, kh1 = t1 >= 6 ? 2 : t1 >= 3 ? 1 : 0, off1 = kh1 * HROW + (t1 - 3 * kh1);
             DIC_HALO_READ_A(0, hb, qb, off1)
-          } else if (cc + 1 < NC) {
+          } else if (cc + 1 < ncj) {
             DIC_HALO_READ_A(0, hb ^ 1, qb, 0)
           } else {
             DIC_HALO_READ_A(0, hb ^ 1, qbn, 0)
@@ -719,7 +759,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
           DIC_HALO_READ_B(0, stn)
         }
         DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0)
-        if (tap == 1 && cc == NC - 1 && j + 1 < ntl) {        // next tile's pixel bases, well before its first fragment reads
+        if (tap == 1 && cc == ncj - 1 && j + 1 < nwork) {     // next tile's pixel bases, well before its first fragment reads
           int tm, tn; tile_of(j + 1, tm, tn);
           qbn[0] = pixel_base(tm, 0); qbn[1] = pixel_base(tm, 1);
         }
@@ -728,35 +768,40 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
         st = stn;
       }
     }
-    // ---- seam
+    // ---- seam (the piece of a remainder tile: same stores into this wave's [64][64] slab of raw partial sums in tail_ws;
+    // rows past M hold junk there, the fix-up masks them)
+    const bool piece = j >= ntl;
     int tm, tn;
     tile_of(j, tm, tn);
-    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    const bool full = piece || ((tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N);
+    const int n0 = piece ? (lane & 31) : tn * BN + wn * 64 + (lane & 31), m0 = piece ? 4 * h : tm * BM + wm * 64 + 4 * h;
+    float* const Cb = piece ? p.tail_ws + ((long long)(((int)blockIdx.x / p.tail_split) * 4 + wave) * p.tail_split + (int)blockIdx.x % p.tail_split) * (64 * 64)
+                            : p.ep.C;
+    const long long ldc = piece ? 64 : p.ep.ldc;
     float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        float* col = Cb + (long long)(m0 + i * 32) * ldc + n0 + jj * 32;
         if (full) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+            col[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][jj][r];
             cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N) {   // rows past M repeat the last pixel: masked
-              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+              col[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][jj][r];
               cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
       }
-    if (p.ep.stats) {
+    if (p.ep.stats && !piece) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
@@ -790,6 +835,8 @@ static int g_bf3_persist_grid = 224;   // persistent kernels: at most this many 
 static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the LDS-halo kernel: 0 = off (code 75), 1 = from 128 tiles (78, default), 2 = always (74)
 static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
+static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
+static int g_bf3_remainder_grid = 256; // ... and the workgroups such a launch may use
 #ifdef DIC_EXPERIMENTS
 static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
 static int g_bf3_ws256 = 0;            // codes 80 / 81: 256x128 form of the warp-specialised kernel by policy on / off (measured 4-7 % SLOWER; 26 forces it)
@@ -808,6 +855,14 @@ static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
   hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 2>), dim3(blocks), dim3(256), 0, st, p);
 }
 
+// Workgroups per persistent launch (dic_conv_persistent_grid, include/dic.h): a launch never asks for more than this many CUs,
+// so that the convolutions of SEVERAL ResNet forwards in flight (engine.py) run side by side instead of taking turns.
+int gemm_bf3_set_persist_grid(int workgroups) {
+  if (workgroups < 1 || workgroups > 1024) return -1;
+  g_bf3_persist_grid = workgroups;
+  return 0;
+}
+
 int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this build
   if (code == 70 || code == 73) { g_bf3_persist_policy = code - 70; return 0; }
   if (code == 79) { g_bf3_persist_policy = 4; return 0; }
@@ -818,6 +873,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 76) return 0;                                      // warp-specialised persistent kernel: the only form of the product
 #endif
   if (code == 20 || code == 11 || code == 21 || code == 24) { g_bf3_force = code == 20 ? 0 : code; return 0; }
+  if (code == 90 || code == 91) { g_bf3_remainder_split = code - 90; return 0; }      // remainder-round K split of the persistent kernels off / on (default)
 #ifdef DIC_EXPERIMENTS
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
@@ -919,11 +975,34 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   const bool im = p.A.kind == OPK_IM2COL;
+  // Remainder-round K split of the persistent 128x128 kernels: T tiles on G workgroups leave T mod G tiles for a last, partly
+  // filled round.  Those r tiles are cut into `sp` K slices (1x1 / gathered: K tiles; halo: channel chunks) handed to the first
+  // r * sp workgroups as one extra piece each, and finished by the tail fix-up (slice sums in K order + epilogue + BatchNorm
+  // partials; deterministic).  Taken when it shortens the longest workgroup by at least a fifth of a tile.
+  int persist_grid = 0, rem128 = 0;
+  if (persist && !ws256 && g_bf3_ablate == 0 && (halo || g_bf3_ws)) {
+    persist_grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
+    const int units = halo ? cg.C / BK3 : nk;                 // what a slice is made of
+    const int gmax = g_bf3_remainder_grid;                     // CUs a split launch may use
+    const int r = T % gmax, fullr = T / gmax;
+    if (g_bf3_remainder_split && tail_ws && plain_ep && fullr >= 1 && r > 0 && units >= 4) {
+      // tail_ws holds kGemmTailWsBytes = 256 slabs of [64][64] floats, a piece writes four (one per consumer wave): r * sp <= 64
+      constexpr int kSlabs = (int)(kGemmTailWsBytes / (64 * 64 * sizeof(float)));
+      int sp = std::min(std::min(std::min(gmax / r, units / 2), 16), kSlabs / 4 / r);
+      while (sp > 1 && (sp - 1) * ceil_div(units, sp) >= units) --sp;      // no empty slice
+      const double longest_now = (double)ceil_div(T, persist_grid);
+      const double longest_split = fullr + (sp > 1 ? (double)ceil_div(units, sp) / units : 1.0) + 0.15;     // + the fix-up launch
+      if (sp >= 2 && r * sp <= gmax && r * 4 * sp <= kSlabs && longest_split + 0.2 <= longest_now) {
+        persist_grid = gmax; rem128 = r;
+        p.tail_first_tile = T - r; p.tail_split = sp; p.tail_ws = tail_ws;
+      }
+    }
+  }
   gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
   if (persist && (halo || !ws256) && (halo || g_bf3_ws) && g_bf3_ablate == 0) {      // the product's 128x128 kernels
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
-    const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
+    const int grid = persist_grid;
     if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<0>, dim3(grid), dim3(512), 0, st, p);
     else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
@@ -967,6 +1046,13 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   else { if (im) launch_bf3_variant<OPK_IM2COL, 1, 1>(p, total, st); else launch_bf3_variant<OPK_ROWK, 1, 1>(p, total, st); }
   DIC_LAUNCH_CHECK();
   gemm_profile_mark_end(st);
+  if (rem128 > 0) {        // finish the remainder tiles of a persistent launch (quadrant-wise: the fix-up works on 64x64 tiles)
+    GemmParams g{};
+    g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.ep.alpha = 1.0f; g.mtiles = ceil_div(p.M, 64); g.ntiles = ceil_div(p.N, 64);
+    g.tail_split = p.tail_split; g.tail_ws = p.tail_ws;
+    g.tail128_first = p.tail_first_tile; g.tail128_ntiles = p.ntiles;
+    DIC_TRY(gemm_launch_tail_fixup(g, rem128 * 4, st));
+  }
   if (tail_tiles > 0) {
     GemmParams g{};
     g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.ep.alpha = 1.0f; g.mtiles = p.mtiles; g.ntiles = p.ntiles;

@@ -353,6 +353,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   70 73 79     persistent kernel by policy: never / 1x1 convolutions by CU fill / + gathered convolutions (default)
  *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
  *   76           accepted, no effect (the persistent kernel's only form here is the warp-specialised one)
+ *   90 91        remainder-round K split of the persistent kernels: off / on (default)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
  * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes
@@ -360,6 +361,11 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,
  * 5 = persistent warp-specialised 128x128, 6 = LDS-halo 3x3 (experiments: 4 = deep-pipelined, 7 = 256x128, 8 = computing-wave DMA). */
 int dic_debug_force_staged_gemm(int on);
+/* Tuning knob (process-global): the persistent split-bf16 convolution kernels (one workgroup per CU, each walking several output
+ * tiles) launch at most `max_workgroups` workgroups.  Default 224.  A small value (e.g. 49: every ResNet-152 layer at batch
+ * 64 has a multiple of 49 tiles) lets the convolutions of several forwards in flight on different streams occupy disjoint
+ * CUs at the same time instead of taking turns on the whole chip; results do not depend on it (same per-tile arithmetic). */
+int dic_conv_persistent_grid(int max_workgroups);
 int dic_profile_begin(void);
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
 

@@ -314,3 +314,65 @@ def test_conv3x3_halo_kernel_vs_fp64_and_gather(lib, B, Cin, CO):
     for c in res:
         assert torch.allclose(res[c][1][0], ref.sum(0), rtol=1e-4, atol=1e-3 * scale), c
         assert torch.allclose(res[c][1][1], (ref * ref).sum(0), rtol=1e-4, atol=1e-3 * scale), c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3])
+def test_persistent_kernels_remainder_round_k_split(lib, k):
+    """Remainder-round K split of the persistent 128x128 kernels (csrc/gemm_bf3.hip, launch_bf3).  3x3 (LDS-halo kernel): 274
+    output tiles (89 images of 14x14, 256 -> 256 channels; the last tile ragged) = one full round of 256 workgroups + 18
+    remainder tiles.  1x1 (warp-specialised kernel; ResNet layer 3 conv3 at batch 64): 784 tiles (64 images, 256 -> 1024) =
+    three rounds + 16.  The remainder tiles are cut into K slices (1x1: 4 slices of two K tiles; 3x3: 3 slices of channel
+    chunks - the 4-MB tail workspace holds 256 [64][64] slabs, four per piece) and finished by the tail fix-up in its 128x128 mode.  Against the same launch without the split (code 90) and an fp64 convolution:
+    output error <= 2x the unsplit kernel's, train-mode BatchNorm partial sums = column sums / sums of squares of the stored
+    output, bit-reproducible over repetitions, and the slices really went through the workspace."""
+    import torch.nn.functional as F
+    B, H, Cin, CO = (89, 14, 256, 256) if k == 3 else (64, 14, 256, 1024)
+    rem, slices = (18, 3) if k == 3 else (16, 4)              # remainder tiles of the 256-workgroup grid, K slices each
+    g = torch.Generator().manual_seed(70 + k)
+    x = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    w = (torch.randn(CO, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
+
+    def split(x2d):
+        R, K = x2d.shape
+        out = [torch.empty((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3)]
+        check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+        return out
+
+    xp, wp = split(x.view(-1, Cin)), split(w.view(CO, -1))
+    planes = lambda ps: (C.c_void_p * 3)(*[t.data_ptr() for t in ps])                    # noqa: E731
+    M = B * H * H
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), padding=k // 2).permute(0, 2, 3, 1).reshape(M, CO)
+    scale = float(ref.abs().max())
+    tail = torch.full((256 * 64 * 64 + 4096,), float("nan"), device=DEV)      # the documented 4 MB + a guard slab
+    res, touched = {}, {}
+    try:
+        for code in (90, 91):                                   # remainder split off / on
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            tail.fill_(float("nan"))
+            for rep in range(3):
+                y = torch.full((M, CO), float("nan"), device=DEV)
+                part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+                mt = C.c_int(0)
+                check(lib.dic_debug_conv_bf3(planes(xp), B, H, H, Cin, planes(wp), CO, k, 1, k // 2, ptr(y), ptr(part), C.byref(mt), ptr(tail),
+                                             stream_ptr()), "dic_debug_conv_bf3")
+                torch.cuda.synchronize()
+                assert torch.isfinite(y).all()
+                stats = part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu()
+                if code in res:
+                    assert torch.equal(res[code][0], y), f"code {code}: repetition {rep} differs"
+                res[code] = (y, stats)
+            touched[code] = int(torch.isfinite(tail).sum())
+    finally:
+        lib.dic_debug_force_staged_gemm(91)
+    assert touched[90] == 0 and touched[91] == rem * 4 * slices * 64 * 64, touched      # remainder tiles x 4 quadrants x slices
+    assert not torch.isfinite(tail[256 * 64 * 64:]).any(), "wrote past the 4-MB tail workspace"
+    err = {c: float((res[c][0].double().cpu() - ref).abs().max()) / scale for c in res}
+    assert err[91] <= 2.0 * err[90] + 1e-6 and err[91] < 5e-6, err
+    ntn = CO // 128
+    first_rem_row = ((M + 127) // 128 * ntn - rem) // ntn * 128      # rows of the tiles finished whole (tile = row block x column block)
+    assert torch.equal(res[90][0][:first_rem_row], res[91][0][:first_rem_row])      # whole tiles: the same kernel code, bit for bit
+    for c in res:
+        yd = res[c][0].double().cpu()
+        assert torch.allclose(res[c][1][0], yd.sum(0), rtol=1e-5, atol=1e-4 * scale), c
+        assert torch.allclose(res[c][1][1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * scale), c
