@@ -27,7 +27,8 @@ int conv_mtiles(const ConvDesc& d, int force_tile = 0);
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st,
                  const float* bias = nullptr, const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr,
-                 int act = 0 /* ACT_NONE */);
+                 int act = 0 /* ACT_NONE */, int tail_ws_slabs = 256 /* [64][64]-float slabs in tail_ws (kGemmTailWsBytes = 256) */);
+constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a larger tail region: every CU can take a remainder piece
 // bn_fuse: when the launch is tail-split, finalize the train-mode BatchNorm inside the fix-up launch (*bn_fused = 1)
 // data gradient of a stride-1 convolution through the same kernel: dy planes [B,OH,OW,CO], flipped weights
 // [C][KH][KW][CO] planes (conv_flip_weights + split), dx fp32 [B,H,W,C]

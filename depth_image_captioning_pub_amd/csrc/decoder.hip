@@ -242,27 +242,51 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float* __restrict__ b_full, const float* __restrict__ WbT, const float* __restrict__ b_beta,
     int t, int T, int mode, const float* __restrict__ gumbel_u, int B, float temp,
     float* __restrict__ alphas, float* __restrict__ Qall, float* __restrict__ ctx_all,
-    float* __restrict__ gate_all, float* __restrict__ Xall, int do_gate, const FusedLstm fl) {
-  // Every phase issues all of its independent loads before the first use (a step is a chain of short phases, each
-  // one memory round trip deep): q 32 loads/thread, scores 13 x 16 B, context + gate 2 x (13 x 16 B + 32 x 4 B).
+    float* __restrict__ gate_all, float* __restrict__ Xall, int do_gate, const FusedLstm fl, const int nrows) {
+  // A step is a chain of short phases; what it costs is memory round trips, not bytes.  So every load whose ADDRESS does not
+  // depend on the previous phase is issued as early as registers allow (round 3): the W_h slice goes out together with the
+  // LSTM slabs at the very top, the P rows under the q phase; the W_beta slice (its product needs only h) streams in two
+  // batches under the q / score / softmax phases; the F rows (whose weights, not addresses, come from the softmax) are in
+  // flight while the softmax runs (compact layout: all of them; 196 cells: the first half).  Per-element arithmetic and summation orders are those of the round-1 kernel.
   __shared__ float h_s[kH];
   __shared__ float q_s[4][kA];
   constexpr int NPS = (L + 15) / 16;                 // score passes: 16 cells (half-waves) per pass
   constexpr int NB = ((L + 7) / 8 + 1) / 2;          // context loop: two batches of NB cells per wave (8 waves)
   constexpr int EP = 16 * NB;                        // padded cell count of the context loop
+  constexpr bool kCompact = L <= 64;                 // 49 cells: P rows and BOTH F batches fit in registers ahead of their use
   __shared__ float e_s[EP];
   __shared__ float red_s[16];
   __shared__ __align__(16) float cred[8][256];
   __shared__ float gp_s[2][256];
-  const int chunk = blockIdx.x, b = blockIdx.y;
+  // Workgroup (chunk, b) owns channels [chunk*256, +256) of batch row b.  The eight chunk workgroups of a row share its P
+  // rows and LSTM slabs (each recomputes scores and cell): they are mapped to dispatch ids with equal id % 8, i.e. to ONE
+  // XCD under round-robin placement (speed only), so those bytes leave HBM / the Infinity Cache once per row, not eight times.
+  const int lin = blockIdx.y * kNCH + blockIdx.x;
+  const int b = (lin & 7) + 8 * (lin >> 6), chunk = (lin >> 3) & 7;
+  if (b >= nrows) return;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave index as a scalar: every address below is (uniform base) + (small per-lane offset), which keeps the
   // many loads in flight from costing a 64-bit address register pair each
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long bt = (long long)b * T + t;
+  const int l32 = lane & 31, hw = w * 2 + (lane >> 5);
+  const bool lstm_only = fl.slab && b >= fl.nb_cur;              // row finished at t-1: only chunk 0 completes its last cell
+  if (lstm_only && chunk != 0) return;
+
+  // ---- early load (compact layout): q weights (W_h^T quarter of this wave), in flight together with the LSTM slabs
+  float wv[32];
+  float4 p4[NPS];
+  const int quarter = w >> 1;
+  const float* Pu = P + (long long)b * L * kA;                       // uniform
+  const float* Wq = WhT + quarter * 32 * kA + (w & 1) * 64;
+  if constexpr (kCompact) {
+    if (!lstm_only) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wv[k] = Wq[k * kA + lane];
+    }
+  }
 
   if (fl.slab) {               // h_t = LSTM cell of step t-1 (see FusedLstm)
-    if (b >= fl.nb_cur && chunk != 0) return;              // row finished at t-1: only chunk 0 completes its last cell
     if (tid < kH) {
       const int j = tid, tp = t - 1;
       float pre[4];
@@ -293,18 +317,36 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
         fl.Hdrop[((long long)fl.packed_off_prev + b) * kH + j] = h * dm;
       }
     }
-    if (b >= fl.nb_cur) return;                            // (whole workgroup: b is uniform)
+    if (lstm_only) return;                                 // (whole workgroup: b is uniform)
   } else if (tid < kH) {
     h_s[tid] = Hall[((long long)b * (T + 1) + t) * kH + tid];
   }
   if (tid >= 256 && tid < 256 + (EP - L)) e_s[L + tid - 256] = 0.f;  // padding cells of the context loop
   __syncthreads();
-  {  // q = Wh h + bh   (four quarters of K per output)
-    const int a = tid & (kA - 1), quarter = w >> 1;
-    const float* Wq = WhT + quarter * 32 * kA + (w & 1) * 64;
-    float wv[32];
+  const int dl = tid & 255, half = w >> 2;
+  const float* Wg = WbT + (long long)(half * 64) * kD + chunk * 256 + (w & 3) * 64;           // uniform
+  const float* Fu = F + (long long)b * L * kD + chunk * 256;                              // uniform
+  const unsigned foff = lane * 4;
+  float wg[32];
+  float4 v0[NB], v1[kCompact ? NB : 1];
+  float gs = 0.f;
+  if constexpr (kCompact) {
+    // gate weights, first half of this wave's K range, and the P rows of the score phase: in flight under the q phase
+    if (do_gate) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wg[k] = Wg[(long long)k * kD + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < NPS; ++i) {     // branch-free guard: cells past the end re-read the last cell (never stored)
+      const unsigned poff = (unsigned)min(hw + 16 * i, L - 1) * kA + l32 * 4;
+      p4[i] = *reinterpret_cast<const float4*>(Pu + poff);
+    }
+  } else {
 #pragma unroll
     for (int k = 0; k < 32; ++k) wv[k] = Wq[k * kA + lane];
+  }
+  {  // q = Wh h + bh   (four quarters of K per output)
+    const int a = tid & (kA - 1);
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) s += wv[k] * h_s[quarter * 32 + k];
@@ -319,16 +361,15 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   if (chunk == 0 && tid < kH && Xall) Xall[bt * kXK + kE + kD + tid] = h_s[tid];   // h_prev slot of the LSTM input
   __syncthreads();
   {  // e[l] = w . relu(P[l,:] + q) + b : one 32-lane half-wave per cell, float4 per lane, 16 cells per pass
-    const int l32 = lane & 31, hw = w * 2 + (lane >> 5);
     const float4 q4 = *reinterpret_cast<const float4*>(&q_s[0][l32 * 4]);
     const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
     const float bf = b_full[0];
-    const float* Pu = P + (long long)b * L * kA;                       // uniform
-    float4 p4[NPS];
+    if constexpr (!kCompact) {
 #pragma unroll
-    for (int i = 0; i < NPS; ++i) {     // branch-free guard: cells past the end re-read the last cell (never stored)
-      const unsigned poff = (unsigned)min(hw + 16 * i, L - 1) * kA + l32 * 4;
-      p4[i] = *reinterpret_cast<const float4*>(Pu + poff);
+      for (int i = 0; i < NPS; ++i) {
+        const unsigned poff = (unsigned)min(hw + 16 * i, L - 1) * kA + l32 * 4;
+        p4[i] = *reinterpret_cast<const float4*>(Pu + poff);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NPS; ++i) {
@@ -339,8 +380,28 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
       if (l < L && l32 == 0) e_s[l] = sc + bf;
     }
   }
+  if constexpr (kCompact) {
+    // the one HBM pass of the step: F[b, :, chunk] (wave w takes cells w, w+8, ...), issued before the softmax that weighs it
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int l = min(w + 8 * i, L - 1);                 // padding cells re-read the last cell, weight e_s = 0
+      v0[i] = *reinterpret_cast<const float4*>(Fu + (long long)l * kD + foff);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int l = min(w + 8 * (NB + i), L - 1);
+      v1[i] = *reinterpret_cast<const float4*>(Fu + (long long)l * kD + foff);
+    }
+    if (do_gate) {             // gate pre-activation, first half of K; then the second half's weights go out
+#pragma unroll
+      for (int k = 0; k < 32; ++k) gs += wg[k] * h_s[half * 64 + k];
+      __builtin_amdgcn_sched_barrier(0);         // (the second half re-uses the registers of the first: keep the order)
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wg[k] = Wg[(long long)(32 + k) * kD + lane];
+    }
+  }
   __syncthreads();
-  {  // attention weights over the 196 cells
+  {  // attention weights over the L cells
     float z = -INFINITY;
     if (tid < L) {
       z = e_s[tid];
@@ -379,35 +440,45 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     }
   }
   __syncthreads();
-  {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk (wave w takes l = w, w+8, ...), fused with the
-     // pre-activation of gate = sigmoid(W_beta h + b) for the same 256 channels (two halves of K per channel)
-    const float* Fu = F + (long long)b * L * kD + chunk * 256;                              // uniform
-    const unsigned foff = lane * 4;
-    const int dl = tid & 255, half = w >> 2;
-    const float* Wg = WbT + (long long)(half * 64) * kD + chunk * 256 + (w & 3) * 64;           // uniform
+  {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk (two batches of NB cells per wave), fused with the pre-activation of
+     // gate = sigmoid(W_beta h + b) for the same 256 channels (two halves of K per channel)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float gs = 0.f;
+    if constexpr (kCompact) {            // everything is in registers already
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const float a = e_s[w + 8 * i];                    // padded with zeros up to EP
+        acc.x += a * v0[i].x; acc.y += a * v0[i].y; acc.z += a * v0[i].z; acc.w += a * v0[i].w;
+      }
+      if (do_gate) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) gs += wg[k] * h_s[half * 64 + 32 + k];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const float a = e_s[w + 8 * (NB + i)];
+        acc.x += a * v1[i].x; acc.y += a * v1[i].y; acc.z += a * v1[i].z; acc.w += a * v1[i].w;
+      }
+    } else {                             // 196 cells: two batches of 13 x 16 B + 32 x 4 B per lane, each one round trip
 #pragma unroll 1
-    for (int bt2 = 0; bt2 < 2; ++bt2) {
-      float4 v[NB];
-      float wv[32];
+      for (int bt2 = 0; bt2 < 2; ++bt2) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int l = min(w + 8 * (bt2 * NB + i), L - 1);      // padding cells re-read the last cell, weight e_s = 0
-        v[i] = *reinterpret_cast<const float4*>(Fu + (long long)l * kD + foff);
-      }
-      if (do_gate) {
+        for (int i = 0; i < NB; ++i) {
+          const int l = min(w + 8 * (bt2 * NB + i), L - 1);
+          v0[i] = *reinterpret_cast<const float4*>(Fu + (long long)l * kD + foff);
+        }
+        if (do_gate) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) wv[k] = Wg[(long long)(bt2 * 32 + k) * kD + lane];
-      }
+          for (int k = 0; k < 32; ++k) wg[k] = Wg[(long long)(bt2 * 32 + k) * kD + lane];
+        }
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const float a = e_s[w + 8 * (bt2 * NB + i)];      // padded with zeros up to EP
-        acc.x += a * v[i].x; acc.y += a * v[i].y; acc.z += a * v[i].z; acc.w += a * v[i].w;
-      }
-      if (do_gate) {
+        for (int i = 0; i < NB; ++i) {
+          const float a = e_s[w + 8 * (bt2 * NB + i)];
+          acc.x += a * v0[i].x; acc.y += a * v0[i].y; acc.z += a * v0[i].z; acc.w += a * v0[i].w;
+        }
+        if (do_gate) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) gs += wv[k] * h_s[half * 64 + bt2 * 32 + k];
+          for (int k = 0; k < 32; ++k) gs += wg[k] * h_s[half * 64 + bt2 * 32 + k];
+        }
       }
     }
     *reinterpret_cast<float4*>(&cred[w][lane * 4]) = acc;
@@ -1159,10 +1230,10 @@ static int decoder_fwd_impl(const dic_decoder_weights* w, int V, const float* fe
                      pl.off[t - 1]};
       rows = pl.bs[t - 1];
     }
-    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_fwd_kernel<L_>, dim3(kNCH, rows), dim3(512), 0, st, ws.F, ws.P, ws.Hall,
+    DIC_CELLS_SWITCH(cells, hipLaunchKernelGGL(attn_fwd_kernel<L_>, dim3(kNCH, (rows + 7) / 8 * 8), dim3(512), 0, st, ws.F, ws.P, ws.Hall,
                                                ws.WhT, w->dec_att_b, w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t,
                                                T, mode, gumbel_u, B, temp, alphas, ws.Qall, ws.ctx, ws.gate, ws.Xall, 1,
-                                               fl);)
+                                               fl, rows);)
     DIC_LAUNCH_CHECK();
     DIC_TRY(gemm_slabs(nb, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
@@ -1401,9 +1472,9 @@ int dic_decoder_greedy(const dic_decoder_weights* w, int V, const float* feat_rg
   DIC_LAUNCH_CHECK();
   for (int t = 0; t < T; ++t) {
     hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(kE), 0, st, w->embed, ws.ids, t, T, V, ws.Xall);
-    hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, B), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
+    hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, (B + 7) / 8 * 8), dim3(512), 0, st, ws.F, ws.P, ws.Hall, ws.WhT, w->dec_att_b,
                        w->full_att_w, w->full_att_b, ws.WbT, w->fbeta_b, t, T, mode, gumbel_u, B, 1.0f, alphas,
-                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1, FusedLstm{});
+                       ws.Qall, ws.ctx, ws.gate, ws.Xall, 1, FusedLstm{}, B);
     DIC_LAUNCH_CHECK();
     DIC_TRY(gemm_slabs(B, kG, kXK, op_rowk(ws.Xall + (long long)t * kXK, (long long)T * kXK), op_rowk(ws.Wcat, kXK),
                        ws.slab_g, kS_LSTM, st));
@@ -1444,10 +1515,10 @@ int dic_attention_fwd(const float* enc_att_w, const float* enc_att_b, const floa
                                  hipMemcpyDeviceToDevice, st));
   DIC_TRY(launch_transpose(dec_att_w, WhT, kA, kH, st));
   DIC_TRY(gemm(B * kL, kA, kD, op_rowk(feats, kD), op_rowk(enc_att_w, kD), ep_store(P, kA, enc_att_b), st));
-  hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, B), dim3(512), 0, st, feats, (const float*)P, (const float*)H2,
+  hipLaunchKernelGGL(attn_fwd_kernel<kL>, dim3(kNCH, (B + 7) / 8 * 8), dim3(512), 0, st, feats, (const float*)P, (const float*)H2,
                      (const float*)WhT, dec_att_b, full_att_w, full_att_b, (const float*)nullptr,
                      (const float*)nullptr, 0, 1, mode, gumbel_u, B, temp, alpha, (float*)nullptr, ctx,
-                     (float*)nullptr, (float*)nullptr, 0, FusedLstm{});
+                     (float*)nullptr, (float*)nullptr, 0, FusedLstm{}, B);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -189,7 +189,7 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov
     for (int j = 0; j < 3; ++j) w.stem_planes[j] = c.take<unsigned short>(conv_stem_bf3_plane_elems(pl.B, pl.H, pl.W));
   w.partial = c.take<float>(pl.max_partial);
   w.red = c.take<double>(pl.max_red);
-  w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
+  w.tail = c.take<float>(std::max((size_t)kResnetTailSlabs * 64 * 64, kGemmTailWsBytes / sizeof(float)));
   w.bn = take_bn(c, 2048);
   w.bn_ds = take_bn(c, 2048);
   w.bytes = c.off;
@@ -222,7 +222,7 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
   const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
                       (double)d.M(), kBnEps, kBnMomentum};
   DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st, nullptr,
-                       (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused));
+                       (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, ACT_NONE, kResnetTailSlabs));
   if (train_bn && fused) return DIC_OK;        // statistics were finalized inside the tail fix-up launch
   if (train_bn)
     return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn,

@@ -888,7 +888,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
 }
 
 static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 1, float* splitk_ws = nullptr,
-                      const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr) {
+                      const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr, int tail_ws_slabs = 256) {
   // tile choice (measured, scripts/bench_bf3.py): bigger per-wave tiles halve the LDS fragment traffic per MFMA and
   // amortise the per-K-tile barrier, but need >= ~2 workgroups per CU to keep 256 CUs busy
   int tmv = 1, tnv = 1;
@@ -986,8 +986,9 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     const int gmax = g_bf3_remainder_grid;                     // CUs a split launch may use
     const int r = T % gmax, fullr = T / gmax;
     if (g_bf3_remainder_split && tail_ws && plain_ep && fullr >= 1 && r > 0 && units >= 4) {
-      // tail_ws holds kGemmTailWsBytes = 256 slabs of [64][64] floats, a piece writes four (one per consumer wave): r * sp <= 64
-      constexpr int kSlabs = (int)(kGemmTailWsBytes / (64 * 64 * sizeof(float)));
+      // tail_ws holds tail_ws_slabs slabs of [64][64] floats (kGemmTailWsBytes = 256 for callers of the C ABI, 1024 inside the
+      // ResNet workspace); a piece writes four (one per consumer wave): r * sp <= slabs / 4
+      const int kSlabs = tail_ws_slabs;
       int sp = std::min(std::min(std::min(gmax / r, units / 2), 16), kSlabs / 4 / r);
       while (sp > 1 && (sp - 1) * ceil_div(units, sp) >= units) --sp;      // no empty slice
       const double longest_now = (double)ceil_div(T, persist_grid);
@@ -1070,7 +1071,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias,
-                 const BnFuseArgs* bn_fuse, int* bn_fused, int act) {
+                 const BnFuseArgs* bn_fuse, int* bn_fused, int act, int tail_ws_slabs) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
   Bf3Params p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -1081,7 +1082,7 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.ep = ep_store(y, d.CO, bias, act);
   p.ep.stats = bn_partial;
   if (bn_fused) *bn_fused = 0;
-  DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused));
+  DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
   return DIC_OK;
 }
