@@ -411,6 +411,19 @@ def main():
     #      them so the collectives stay matched) ----
     cells = int(trainer.last["features"].shape[1]) if trainer.last.get("features") is not None else 196
     torch.cuda.synchronize()
+    # ---- stage times of the main stream UNDER LOAD: five more pipelined steps with stage-boundary events (one host sync per
+    #      step, so these steps are not part of `value`); the same stages alone on the chip are `stages_ms` below
+    under_load = {}
+    if not args.no_overlap:
+        trainer.timing = True
+        for _ in range(5):
+            trainer.train_step(*step_args, **pipe)
+            torch.cuda.synchronize()
+            for k, v in trainer.stage_ms().items():
+                under_load[k] = under_load.get(k, 0.0) + v / 5
+        trainer.timing = False
+        if world > 1:
+            torch.distributed.barrier()
     trainer.prefetched = None         # the stage-timed step runs its own ResNet forward on the main stream (no overlap)
     trainer.timing = (rank == 0)
     trainer.train_step(*step_args)
@@ -496,6 +509,10 @@ def main():
             "stages_note": "one extra un-overlapped step after the timed region: every stage on the main stream, incl. "
                            "the ResNet-152 forward that the timed steps run on the side stream",
             "overlap_hidden_ms": round(sum(stages.values()) - ms_step, 3) if not args.no_overlap else 0.0,
+            "stages_under_load_ms": {k: round(v, 3) for k, v in under_load.items()} if under_load else None,
+            "stages_under_load_note": "the same stage boundaries inside the pipelined step (mean of 5 extra steps with a host sync "
+                                      "each): the main stream next to the ResNet forwards in flight on the side streams; "
+                                      "'resnet152_fwd' there is only the wait for the prefetched features",
             "roofline": roofline, "decoder_roofline": decoder_roofline,
             "other_conv_mode": alt,
         }

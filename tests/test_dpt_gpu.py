@@ -146,3 +146,64 @@ def test_training_loop_with_dpt_front_end_and_depth_cache(lib, tmp_path):
     assert stats == {"prefetch_dropped": 0, "dpt_forwards": 2, "cache_hits": 2, "cache_entries": 4,
                      "val_dpt_forwards": 1, "val_cache_hits": 1, "val_cache_entries": 2}
     assert len(hist) == 2 and all(np.isfinite(v) for pair in hist for v in pair)
+
+
+def test_config5_full_size_dpt_feeds_full_size_train_step(lib):
+    """BASELINE config 5 end to end at full size, per rank of an 8-GPU run: a raw batch of 8 images -> the two device transforms
+    (util.py:100-101) -> the full DPT-Hybrid estimator at 384x384 (122 M parameters) -> standardise -> Resize(224)
+    (depth_train.py:185-190) -> one depth-soft training step with the full ResNet-152 (batch-statistics BatchNorm), V = 10 000,
+    seq-len 20, explicit dropout mask.  Against the CPU oracles chained the same way (oracle/dpt_oracle.py ->
+    oracle/captioning_oracle.py): the depth maps, then the step's loss end to end (1e-4), and - the oracle step fed with the HIP
+    path's own depth maps and ResNet features - loss 1e-5, logits 1e-4, token-id argmax identical on every row.
+    PARITY UNPINNED for the DPT part (timm absent, see the top of this file): this pins the plumbing and the numerics of the
+    chain against the restatement, not against the reference's checkpoint."""
+    import copy
+    from depth_image_captioning_pub_amd.Captioning_models import util
+    from depth_image_captioning_pub_amd.engine import CaptionTrainer
+    from oracle import captioning_oracle as corc
+    B, V, T = 8, 10000, 20
+    cfg = syn.DptConfig()
+    dpt = DPT_Depthestimator(cfg, seed=131).to(DEV)
+    raw = syn.raw_images(B, seed=77).to(DEV)
+    imgs, imgs_for_dep = util.device_transforms(raw)
+    assert tuple(imgs_for_dep.shape) == (B, 3, 384, 384)
+    depth = dpt.depth_maps_for_training(imgs_for_dep)                        # [B,1,224,224] in [0,1]
+    dec = syn.decoder_weights(V, seed=123)
+    enc, st = syn.depth_encoder_weights(seed=124)
+    rn = syn.resnet152_weights(seed=125)
+    caps, lens = syn.captions_fixed(B, V, T, seed=77)
+    drop = syn.dropout_multiplier(B, T, 0.5, seed=77)
+    tr = CaptionTrainer(V, device=DEV, seed=123, decoder_init=dec, depth_init=enc, depth_state=copy.deepcopy(st),
+                        resnet_init=copy.deepcopy(rn), conv_mode="bf16x3")
+    tr.keep_outputs = True
+    loss = tr.train_step(imgs, depth, caps.to(DEV), lens, drop_mult=drop.to(DEV), apply_update=False)
+    torch.cuda.synchronize()
+    loss = float(loss.item())
+    # ---- the oracles, chained
+    w = {k[len("model."):]: v.cpu() for k, v in dpt.state_dict().items()}
+    depth_ref = orc.depth_front_end(w, imgs_for_dep.cpu(), cfg)
+    e = _err(depth, depth_ref)
+    print(f"\nconfig 5: depth maps max err {e:.2e} of scale {float(depth_ref.max()):.3f}")
+    assert e <= 1e-3
+    feats_ref = corc.resnet152_features(copy.deepcopy(rn), imgs.cpu(), train_bn=True)
+    own = corc.train_step_soft(dec, enc, copy.deepcopy(st), feats_ref, depth_ref, caps, lens, drop)
+    print(f"config 5: loss {loss:.6f} vs chained oracles {float(own[0]):.6f}")
+    assert abs(loss - float(own[0])) <= 1e-4
+    # ---- the captioning oracle on the HIP path's depth maps and ResNet features
+    feats = tr.last["features"].cpu()
+    f196 = feats if feats.shape[1] == 196 else feats.reshape(B, 7, 7, 2048).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(B, 196, 2048)
+    from depth_image_captioning_pub_amd import native
+    compact = feats.shape[1] == 49                      # replay the HIP path's ReLU / max-pool selections (tie-breaks), as in
+    dec_sel = {k: v.cpu() for k, v in native.depth_encoder_decisions(      # tests/test_fullsize_parity_gpu.py stage B
+        native.DepthTape(tr.enc_ws, depth, tr.enc_w, compact)).items()}
+    att = native.decoder_attention_relu_mask(tr.last["decoder_tape"]).cpu()
+    if att.shape[2] == 49:
+        att = att.reshape(B, T, 7, 7, -1).repeat_interleave(2, 2).repeat_interleave(2, 3).reshape(B, T, 196, -1)
+    rep = {}
+    same = corc.train_step_soft(dec, enc, copy.deepcopy(st), f196, depth.cpu(), caps, lens, drop, decisions=dec_sel, report=rep,
+                                att_masks=att)
+    assert all(short <= 3e-5 for _, short in rep.values()), rep
+    assert abs(loss - float(same[0])) <= 1e-5, (loss, float(same[0]))
+    logits = tr.last["logits"]
+    assert _err(logits, same[1]) <= 1e-4
+    assert torch.equal(logits.argmax(1).cpu(), same[1].argmax(1)), "token-id argmax must be identical on every row"
