@@ -253,6 +253,217 @@ __global__ void __launch_bounds__(256) vit_attention_kernel(const float* __restr
   }
 }
 
+// ---- the same attention on the matrix cores (round 3): split-bf16 arithmetic as in gemm_bf3.hip (hi + mid + lo planes, six
+// products per fp32 product, fp32 accumulate), v_mfma_f32_16x16x32_bf16.
+//   pre-pass (vit_split_kv_kernel, once per layer): K of every (image, head) as planes Kp[3][Npad][64] (rows = keys) and V
+//   TRANSPOSED as planes VTp[3][64][Npad] (rows = head-dim index), zero-padded to Npad = 64 * ceil(N / 64).  Inside a 64-key
+//   tile the columns of VTp are permuted: column 32s + 8g + 4h + j holds key 32s + 16h + 4g + j.  Reason below.
+//   main kernel: a workgroup = 64 queries of one (image, head), wave w = queries 16w .. 16w+15.  Everything is laid out so
+//   that a LANE BELONGS TO ONE QUERY (q = lane & 15) in both products, which makes the online softmax lane-local:
+//     S^T = K Q^T : A = K block (16 keys x 32 d, from LDS), B = Q (registers, loaded once)  ->  C: lane (q, g) holds keys 4g+j
+//     O^T = V^T P^T: A = V^T block (16 d x 32 keys, from LDS), B = P                         ->  C: lane (q, g) holds d 4g+j
+//   The B operand of the second product needs, per lane (q, g) and 32-key step s, eight probabilities of query q as k-slots
+//   8g .. 8g+7: exactly the lane's own S^T values of key blocks 2s (j = 0..3) and 2s+1 - no shuffle, no LDS round trip -
+//   provided the A operand uses the same slot -> key assignment, which is what the column permutation of VTp does.
+constexpr int kAtLd = 72;     // LDS row stride in bf16 (144 B: the 16 rows of a fragment read start in 16 different 16-B bank groups)
+
+__global__ void __launch_bounds__(256) vit_split_kv_kernel(const float* __restrict__ qkv, int N, int heads, int Npad,
+                                                            unsigned short* __restrict__ Kp, unsigned short* __restrict__ VTp) {
+  __shared__ float vt[64][65];
+  const int kt = blockIdx.x, hh = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const long long row_stride = (long long)3 * heads * kHd;
+  const float* base = qkv + (long long)b * N * row_stride + (long long)hh * kHd;
+  const long long bh = (long long)b * heads + hh;
+  const size_t plane = (size_t)Npad * kHd;
+  unsigned short* kp = Kp + bh * 3 * plane;
+  unsigned short* vp = VTp + bh * 3 * plane;
+  {   // thread = (key r, 16 head-dim values): K planes row-major; V into LDS for the transpose
+    const int r = tid >> 2, c = (tid & 3) * 16, key = kt * 64 + r;
+    float kv[16], vv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), d = a;
+      if (key < N) {
+        const float* src = base + (long long)key * row_stride + c + i * 4;
+        a = *reinterpret_cast<const float4*>(src + (long long)heads * kHd);
+        d = *reinterpret_cast<const float4*>(src + (long long)2 * heads * kHd);
+      }
+      kv[i * 4] = a.x; kv[i * 4 + 1] = a.y; kv[i * 4 + 2] = a.z; kv[i * 4 + 3] = a.w;
+      vv[i * 4] = d.x; vv[i * 4 + 1] = d.y; vv[i * 4 + 2] = d.z; vv[i * 4 + 3] = d.w;
+    }
+    unsigned short h[16], m[16], l[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { split3_bf16(kv[i], h[i], m[i], l[i]); vt[r][c + i] = vv[i]; }
+    unsigned short* dst = kp + (size_t)key * kHd + c;
+    auto pack = [](const unsigned short* x, int o) { return (unsigned)x[o] | ((unsigned)x[o + 1] << 16); };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<uint4*>(dst + q * 8) = make_uint4(pack(h, q * 8), pack(h, q * 8 + 2), pack(h, q * 8 + 4), pack(h, q * 8 + 6));
+      *reinterpret_cast<uint4*>(dst + plane + q * 8) = make_uint4(pack(m, q * 8), pack(m, q * 8 + 2), pack(m, q * 8 + 4), pack(m, q * 8 + 6));
+      *reinterpret_cast<uint4*>(dst + 2 * plane + q * 8) = make_uint4(pack(l, q * 8), pack(l, q * 8 + 2), pack(l, q * 8 + 4), pack(l, q * 8 + 6));
+    }
+  }
+  __syncthreads();
+  {   // thread = (head-dim index d, 16 permuted columns): V^T planes
+    const int d = tid >> 2, p0 = (tid & 3) * 16;
+    unsigned short h[16], m[16], l[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int pp = p0 + i, s2 = pp >> 5, g = (pp >> 3) & 3, hsel = (pp >> 2) & 1, j = pp & 3;
+      split3_bf16(vt[32 * s2 + 16 * hsel + 4 * g + j][d], h[i], m[i], l[i]);
+    }
+    unsigned short* dst = vp + (size_t)d * Npad + kt * 64 + p0;
+    auto pack = [](const unsigned short* x, int o) { return (unsigned)x[o] | ((unsigned)x[o + 1] << 16); };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<uint4*>(dst + q * 8) = make_uint4(pack(h, q * 8), pack(h, q * 8 + 2), pack(h, q * 8 + 4), pack(h, q * 8 + 6));
+      *reinterpret_cast<uint4*>(dst + plane + q * 8) = make_uint4(pack(m, q * 8), pack(m, q * 8 + 2), pack(m, q * 8 + 4), pack(m, q * 8 + 6));
+      *reinterpret_cast<uint4*>(dst + 2 * plane + q * 8) = make_uint4(pack(l, q * 8), pack(l, q * 8 + 2), pack(l, q * 8 + 4), pack(l, q * 8 + 6));
+    }
+  }
+}
+
+typedef __bf16 dpt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float dpt_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int dpt_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ dpt_f32x4 dpt_mfma6(const dpt_u32x4 a[3], const dpt_u32x4 b[3], dpt_f32x4 c) {
+  // small terms first, as in gemm_bf3.hip: al*bh, ah*bl, am*bm, am*bh, ah*bm, ah*bh   (0 = hi, 1 = mid, 2 = lo)
+#define DIC_M(A_, B_) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dpt_bf16x8, a[A_]), __builtin_bit_cast(dpt_bf16x8, b[B_]), c, 0, 0, 0);
+  DIC_M(2, 0) DIC_M(0, 2) DIC_M(1, 1) DIC_M(1, 0) DIC_M(0, 1) DIC_M(0, 0)
+#undef DIC_M
+  return c;
+}
+
+__global__ void __launch_bounds__(256, 2) vit_attention_mfma_kernel(const float* __restrict__ qkv, int N, int heads, int Npad,
+                                                                     float scale, const unsigned short* __restrict__ Kp,
+                                                                     const unsigned short* __restrict__ VTp,
+                                                                     float* __restrict__ out) {
+  __shared__ __align__(16) unsigned short Ks[3][64][kAtLd], Vs[3][64][kAtLd];      // 27.6 KB each
+  const int qt = blockIdx.x, hh = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ql = lane & 15, g = lane >> 4;
+  const long long row_stride = (long long)3 * heads * kHd;
+  const long long bh = (long long)b * heads + hh;
+  const size_t plane = (size_t)Npad * kHd;
+  const unsigned short* kp = Kp + bh * 3 * plane;
+  const unsigned short* vp = VTp + bh * 3 * plane;
+  const int q = qt * 64 + w * 16 + ql;
+
+  dpt_u32x4 qf[2][3];          // Q fragments (B operand of S^T = K Q^T): k-slots 8g .. 8g+7 of d-step s, pre-scaled (exact: 1/8)
+  {
+    const float* src = qkv + ((long long)b * N + min(q, N - 1)) * row_stride + (long long)hh * kHd;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float4 x0 = *reinterpret_cast<const float4*>(src + 32 * s2 + 8 * g), x1 = *reinterpret_cast<const float4*>(src + 32 * s2 + 8 * g + 4);
+      const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      unsigned short h[8], m[8], l[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) split3_bf16(q < N ? v[i] * scale : 0.f, h[i], m[i], l[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        qf[s2][0][i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
+        qf[s2][1][i] = (unsigned)m[2 * i] | ((unsigned)m[2 * i + 1] << 16);
+        qf[s2][2][i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
+      }
+    }
+  }
+  float mrow = -INFINITY, lrow = 0.f;
+  dpt_f32x4 ot[4];              // O^T: d = 16 db + 4 g + j of query q
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ot[i] = dpt_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = Npad / 64;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();                                        // the previous tile's fragments have been read
+    {   // K and V^T tiles, three planes each: 64 rows x 128 B; thread = (row, 32-B quarter), six planes
+      const int r = tid >> 2, c = (tid & 3) * 16;
+      uint4 x[3][2], y[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short* ks = kp + pl * plane + (size_t)(kt * 64 + r) * kHd + c;
+        const unsigned short* vs = vp + pl * plane + (size_t)r * Npad + kt * 64 + c;
+        x[pl][0] = *reinterpret_cast<const uint4*>(ks); x[pl][1] = *reinterpret_cast<const uint4*>(ks + 8);
+        y[pl][0] = *reinterpret_cast<const uint4*>(vs); y[pl][1] = *reinterpret_cast<const uint4*>(vs + 8);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        *reinterpret_cast<uint4*>(&Ks[pl][r][c]) = x[pl][0]; *reinterpret_cast<uint4*>(&Ks[pl][r][c + 8]) = x[pl][1];
+        *reinterpret_cast<uint4*>(&Vs[pl][r][c]) = y[pl][0]; *reinterpret_cast<uint4*>(&Vs[pl][r][c + 8]) = y[pl][1];
+      }
+    }
+    __syncthreads();
+    // ---- S^T block kb: keys 16 kb + (4 g + j) of this tile, query q
+    dpt_f32x4 st[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      st[kb] = dpt_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        dpt_u32x4 ka[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ka[pl] = *reinterpret_cast<const dpt_u32x4*>(&Ks[pl][kb * 16 + ql][32 * s2 + 8 * g]);
+        st[kb] = dpt_mfma6(ka, qf[s2], st[kb]);
+      }
+    }
+    // ---- online softmax of query q over this tile's 64 keys: 16 values in this lane, the rest in lanes q + 16 g'
+    float tm = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kt * 64 + kb * 16 + 4 * g + j >= N) st[kb][j] = -INFINITY;
+        tm = fmaxf(tm, st[kb][j]);
+      }
+    tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    const float mn = fmaxf(mrow, tm);
+    const float corr = expf(mrow - mn);                     // (first tile: exp(-inf) = 0)
+    float ps = 0.f;
+    dpt_u32x4 pf[2][3];           // P fragments (B operand of O^T = V^T P^T): k-slot 4 h + j of step s = key block 2 s + h, key 4 g + j
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      unsigned short h[8], m[8], l[8];
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pv = expf(st[2 * s2 + hs][j] - mn);
+          ps += pv;
+          split3_bf16(pv, h[4 * hs + j], m[4 * hs + j], l[4 * hs + j]);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pf[s2][0][i] = (unsigned)h[2 * i] | ((unsigned)h[2 * i + 1] << 16);
+        pf[s2][1][i] = (unsigned)m[2 * i] | ((unsigned)m[2 * i + 1] << 16);
+        pf[s2][2][i] = (unsigned)l[2 * i] | ((unsigned)l[2 * i + 1] << 16);
+      }
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    lrow = lrow * corr + ps;
+    mrow = mn;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      ot[db][0] *= corr; ot[db][1] *= corr; ot[db][2] *= corr; ot[db][3] *= corr;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        dpt_u32x4 va[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) va[pl] = *reinterpret_cast<const dpt_u32x4*>(&Vs[pl][db * 16 + ql][32 * s2 + 8 * g]);
+        ot[db] = dpt_mfma6(va, pf[s2], ot[db]);
+      }
+    }
+  }
+  if (q < N) {
+    const float inv = 1.0f / lrow;
+    float* dst = out + ((long long)b * N + q) * heads * kHd + hh * kHd + 4 * g;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<float4*>(dst + 16 * db) = make_float4(ot[db][0] * inv, ot[db][1] * inv, ot[db][2] * inv, ot[db][3] * inv);
+  }
+}
+
 // ---- bilinear x2 up-sampling, align_corners=True, NHWC (FeatureFusionBlock_custom, Interpolate) -------------------
 __global__ void __launch_bounds__(256) upsample2x_nhwc_kernel(const float* __restrict__ x, int H, int W, int C4,
                                                                long long total, float* __restrict__ out) {
@@ -379,11 +590,29 @@ int dic_layernorm(const float* x, long long rows, int C, const float* gamma, con
   return DIC_OK;
 }
 
-int dic_vit_attention(const float* qkv, int B, int N, int heads, int head_dim, float* out, void* stream) {
+size_t dic_vit_attention_workspace_bytes(int B, int N, int heads) {
+  const size_t npad = (size_t)(N + 63) / 64 * 64;
+  return (size_t)B * heads * 2 * 3 * npad * kHd * sizeof(unsigned short);          // K planes + transposed V planes
+}
+
+int dic_vit_attention(const float* qkv, int B, int N, int heads, int head_dim, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
   DIC_REQUIRE(qkv && out && B > 0 && N > 0 && heads > 0, "vit_attention: bad arguments");
   DIC_REQUIRE(head_dim == kHd, "vit_attention: head dimension must be 64 (ViT-B/16: 768 / 12)");
-  hipLaunchKernelGGL(vit_attention_kernel, dim3((N + kAt - 1) / kAt, heads, B), dim3(256), 0, (hipStream_t)stream, qkv, N,
-                     heads, 1.0f / sqrtf((float)head_dim), out);
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  if (!workspace) {            // no scratch: plain fp32 FMAs on the vector units (round-2 kernel)
+    hipLaunchKernelGGL(vit_attention_kernel, dim3((N + kAt - 1) / kAt, heads, B), dim3(256), 0, (hipStream_t)stream, qkv, N,
+                       heads, scale, out);
+    DIC_LAUNCH_CHECK();
+    return DIC_OK;
+  }
+  DIC_REQUIRE(workspace_bytes >= dic_vit_attention_workspace_bytes(B, N, heads), "vit_attention: workspace too small");
+  const int ntile = (N + 63) / 64, npad = ntile * 64;
+  unsigned short* Kp = static_cast<unsigned short*>(workspace);
+  unsigned short* VTp = Kp + (size_t)B * heads * 3 * npad * kHd;
+  hipLaunchKernelGGL(vit_split_kv_kernel, dim3(ntile, heads, B), dim3(256), 0, (hipStream_t)stream, qkv, N, heads, npad, Kp, VTp);
+  hipLaunchKernelGGL(vit_attention_mfma_kernel, dim3(ntile, heads, B), dim3(256), 0, (hipStream_t)stream, qkv, N, heads, npad,
+                     scale, (const unsigned short*)Kp, (const unsigned short*)VTp, out);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -241,7 +241,17 @@ class DptRunner:
         h = self.layer_norm(x, p + "norm1.")
         qkv = self.linear(h, p + "attn.qkv")
         a = torch.empty_like(x)
-        check(self.lib.dic_vit_attention(ptr(qkv), B, N, self.cfg.heads, Cc // self.cfg.heads, ptr(a), stream_ptr()),
+        # both products of the attention on the matrix cores (split-bf16 arithmetic, fp32 online softmax) when the runner
+        # computes in bf16x3; the exact-fp32 runner keeps the plain fp32 vector kernel (workspace = NULL)
+        ws = None
+        if self.arith == "bf16x3":
+            self.lib.dic_vit_attention_workspace_bytes.restype = C.c_size_t
+            need = self.lib.dic_vit_attention_workspace_bytes(B, N, self.cfg.heads)
+            if getattr(self, "_attn_ws", None) is None or self._attn_ws.numel() < need:
+                self._attn_ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            ws = self._attn_ws
+        check(self.lib.dic_vit_attention(ptr(qkv), B, N, self.cfg.heads, Cc // self.cfg.heads, ptr(a), ptr(ws),
+                                         C.c_size_t(ws.numel() if ws is not None else 0), stream_ptr()),
               "dic_vit_attention")
         self.linear(a, p + "attn.proj", out=x, accumulate=True)
         h = self.layer_norm(x, p + "norm2.")

@@ -314,8 +314,12 @@ int dic_groupnorm_nhwc(const float* x, int B, long long HW, int C, int groups, c
 /* nn.LayerNorm(C, eps) over [rows, C] */
 int dic_layernorm(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* out,
                   void* stream);
-/* timm Attention core: qkv [B,N,3,heads,64] -> softmax(q k^T / 8) v as [B,N,heads*64] */
-int dic_vit_attention(const float* qkv, int B, int N, int heads, int head_dim, float* out, void* stream);
+/* timm Attention core: qkv [B,N,3,heads,64] -> softmax(q k^T / 8) v as [B,N,heads*64].  With `workspace`
+ * (dic_vit_attention_workspace_bytes) both products run on the matrix cores in split-bf16 arithmetic (fp32-level accuracy,
+ * online softmax in fp32); workspace = NULL keeps the plain fp32 vector kernel. */
+size_t dic_vit_attention_workspace_bytes(int B, int N, int heads);
+int dic_vit_attention(const float* qkv, int B, int N, int heads, int head_dim, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=True) on NHWC, C % 4 == 0 (blocks.py:330-334, Interpolate) */
 int dic_upsample2x_bilinear_nhwc(const float* x, int B, int H, int W, int C, float* out, void* stream);
 /* out[i] = act(a[i] + b[i % period]) (b nullable); act 0 none, 1 ReLU, 3 GELU: residual adds, position embedding, ReLUs */

@@ -60,6 +60,40 @@ def test_dpt_operators_vs_torch(lib):
     assert _err(rn.pos_embed(6, 6), orc.resize_pos_embed(w["pretrained.model.pos_embed"], 6, 6)[0]) <= 1e-6
 
 
+@pytest.mark.parametrize("B,N", [(2, 577), (3, 37), (1, 64), (2, 130)])
+def test_vit_attention_matrix_core_kernel_vs_fp64(lib, B, N):
+    """dic_vit_attention: the matrix-core kernel (split-bf16 products, fp32 online softmax; K / V^T planes from the pre-pass)
+    and the plain fp32 vector kernel (workspace = NULL) against softmax(q k^T / 8) v evaluated in fp64, ViT-B/16 geometry
+    (12 heads x 64) - the DPT front-end's 577 tokens, token counts that are not a multiple of the 64-key tile, a single tile.
+    Bar: fp32 level (1e-5 of scale; the two kernels within 2x of each other's error); logits with a large spread so that the
+    online rescaling is exercised."""
+    import ctypes as C
+    from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr
+    heads, hd = 12, 64
+    g = torch.Generator().manual_seed(100 * B + N)
+    qkv = torch.randn(B, N, 3, heads, hd, generator=g)
+    qkv[:, :, 0] *= 3.0                                        # |logits| up to ~30: exp underflow / rescale paths
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).double() for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, N, heads * hd)
+    x = qkv.to(DEV).contiguous()
+    lib.dic_vit_attention_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(lib.dic_vit_attention_workspace_bytes(B, N, heads), dtype=torch.uint8, device=DEV)
+    err = {}
+    for name, w in (("mfma", ws), ("valu", None)):
+        out = torch.full((B, N, heads * hd), float("nan"), device=DEV)
+        for rep in range(2):
+            check(lib.dic_vit_attention(ptr(x), B, N, heads, hd, ptr(out), ptr(w), C.c_size_t(w.numel() if w is not None else 0),
+                                        stream_ptr()), "dic_vit_attention")
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), name
+        err[name] = _err(out, ref)
+    print(f"attention B={B} N={N}: max err / scale {err}")
+    assert err["mfma"] <= 1e-5 and err["valu"] <= 1e-5, err
+    assert err["mfma"] <= 2.0 * err["valu"] + 1e-6, err
+    small = torch.empty(16, dtype=torch.uint8, device=DEV)
+    assert lib.dic_vit_attention(ptr(x), B, N, heads, hd, ptr(out), ptr(small), C.c_size_t(16), stream_ptr()) != 0     # workspace too small
+
+
 @pytest.mark.parametrize("size,batch", [(64, 2), (96, 1)])
 def test_dpt_small_model_vs_oracle(lib, size, batch):
     """A shrunk DPT-Hybrid (one bottleneck per stage, two transformer blocks) end to end, incl. the re-sampled position
