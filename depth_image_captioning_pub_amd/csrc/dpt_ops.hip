@@ -3,9 +3,11 @@
 //   modules/midas/blocks.py:231-341, modules/midas/vit.py:36-155,345-477 and - un-vendored, restated from its published
 //   definition - timm 0.4.12's vit_base_resnet50_384 (ResNetV2 stem with StdConv2dSame + GroupNorm, ViT-B/16 blocks).
 // Forward only (the reference runs it under @torch.no_grad, frozen).  The contractions (convolutions, linear layers) run
-// on the exact-fp32 MFMA kernels of gemm.hip through dic_conv2d_fwd / dic_gemm_f32; this file holds what those do not
-// cover: weight standardisation, asymmetric 'SAME' padding, GroupNorm, LayerNorm, multi-head attention, the bilinear x2
-// up-sampling of the fusion blocks and small element-wise passes.  All activations NHWC / [tokens][channels], fp32.
+// on the split-bf16 kernels of gemm_bf3.hip through dic_conv2d_bf16x3 / dic_linear_bf16x3 (DptRunner's default arithmetic;
+// the 3-channel stem and DptRunner(arith="fp32") use the exact-fp32 MFMA kernels of gemm.hip: dic_conv2d_fwd / dic_gemm_f32);
+// this file holds what those do not cover: weight standardisation, asymmetric 'SAME' padding, GroupNorm, LayerNorm,
+// multi-head attention (matrix cores, split-bf16; round 3), the bilinear x2 up-sampling of the fusion blocks and small
+// element-wise passes.  All activations NHWC / [tokens][channels], fp32.
 #include "dic.h"
 #include "common.h"
 #include "nn_kernels.h"
