@@ -44,7 +44,8 @@ int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsi
 int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned short* const x_planes[3],
                   const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st);
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
-                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st);
+                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st, float* tail_ws = nullptr,
+                      int tail_ws_slabs = 256);
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
                         unsigned short* lo, hipStream_t st);

@@ -106,7 +106,7 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
     w.wg_pT[i] = c.take<unsigned short>(std::max(conv_wgrad_bf3_plane_elems(g.c2, 1), conv_wgrad_bf3_plane_elems(g.c3, 1)));
   }
   w.wg_bf3_ws = c.take<float>(std::max(conv_wgrad_bf3_ws_floats(g.c2, kWg2SplitBf3), conv_wgrad_bf3_ws_floats(g.c3, kWg3SplitBf3)));
-  w.tail = c.take<float>(kGemmTailWsBytes / sizeof(float));
+  w.tail = c.take<float>(std::max((size_t)kResnetTailSlabs * 64 * 64, kGemmTailWsBytes / sizeof(float)));
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
   return w;
@@ -385,7 +385,8 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   {
     const unsigned short* xp[3] = {ws.y1p_pl[0], ws.y1p_pl[1], ws.y1p_pl[2]};
     const unsigned short* wp[3] = {ws.w2_pl[0], ws.w2_pl[1], ws.w2_pl[2]};
-    DIC_TRY(conv_fwd_bf3(xp, g.c2, wp, ws.x2, train ? ws.partial : nullptr, &mt, nullptr, st, w->conv2_b));
+    DIC_TRY(conv_fwd_bf3(xp, g.c2, wp, ws.x2, train ? ws.partial : nullptr, &mt, ws.tail, st, w->conv2_b, nullptr, nullptr,
+                         ACT_NONE, kResnetTailSlabs));
   }
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M2, 512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, ws.red, st));
   else DIC_TRY(bn_finalize_eval(512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
@@ -395,7 +396,8 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   {
     const unsigned short* xp[3] = {ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2]};
     const unsigned short* wp[3] = {ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2]};
-    DIC_TRY(conv_fwd_bf3(xp, g.c3, wp, ws.x3, train ? ws.partial : nullptr, &mt, ws.tail, st, w->conv3_b));
+    DIC_TRY(conv_fwd_bf3(xp, g.c3, wp, ws.x3, train ? ws.partial : nullptr, &mt, ws.tail, st, w->conv3_b, nullptr, nullptr,
+                         ACT_NONE, kResnetTailSlabs));
   }
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, ws.red, st));
   else DIC_TRY(bn_finalize_eval(2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
@@ -436,7 +438,7 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   {
     const unsigned short* dp[3] = {ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2]};
     const unsigned short* wp[3] = {ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2]};
-    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c3, wp, ws.dy2p, st));
+    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c3, wp, ws.dy2p, st, ws.tail, kResnetTailSlabs));
   }
   // layer 2
   DIC_TRY(bn_pool_backward(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b,
@@ -447,7 +449,7 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   {
     const unsigned short* dp[3] = {ws.dy2_pl[0], ws.dy2_pl[1], ws.dy2_pl[2]};
     const unsigned short* wp[3] = {ws.w2f_pl[0], ws.w2f_pl[1], ws.w2f_pl[2]};
-    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c2, wp, ws.dy1p, st));
+    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c2, wp, ws.dy1p, st, ws.tail, kResnetTailSlabs));
   }
   // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
   DIC_TRY(bn_pool_backward(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,

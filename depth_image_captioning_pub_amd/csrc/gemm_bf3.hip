@@ -917,7 +917,15 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && p.N % 128 == 0 && (plain_ep || g_bf3_ws);
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
-  const double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
+  double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
+  {   // ... or, with the remainder-round K split (below), among all of them
+    const int gmax = g_bf3_remainder_grid, r = (int)(t22 % gmax), fullr = (int)(t22 / gmax), units = ceil_div(p.K, BK3);
+    if (g_bf3_remainder_split && tail_ws && splitk <= 1 && fullr >= 1 && r > 0 && units >= 4) {
+      int sp = std::min(std::min(std::min(gmax / r, units / 2), 16), tail_ws_slabs / 4 / r);
+      while (sp > 1 && (sp - 1) * ceil_div(units, sp) >= units) --sp;
+      if (sp >= 2) fill22 = std::max(fill22, (double)t22 / ((fullr + (double)ceil_div(units, sp) / units + 0.15) * gmax));
+    }
+  }
   bool persist = false;
   if (persist_ok && g_bf3_force == 0) {
     if (g_bf3_persist_policy == 1) persist = p.K <= 64 && t22 >= 1024;
@@ -985,7 +993,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     const int units = halo ? cg.C / BK3 : nk;                 // what a slice is made of
     const int gmax = g_bf3_remainder_grid;                     // CUs a split launch may use
     const int r = T % gmax, fullr = T / gmax;
-    if (g_bf3_remainder_split && tail_ws && plain_ep && fullr >= 1 && r > 0 && units >= 4) {
+    if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4) {
       // tail_ws holds tail_ws_slabs slabs of [64][64] floats (kGemmTailWsBytes = 256 for callers of the C ABI, 1024 inside the
       // ResNet workspace); a piece writes four (one per consumer wave): r * sp <= slabs / 4
       const int kSlabs = tail_ws_slabs;
@@ -1241,11 +1249,12 @@ int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned 
 }
 
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
-                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st) {
+                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st, float* tail_ws, int tail_ws_slabs) {
   DIC_REQUIRE(d.stride == 1 && d.CO % 32 == 0, "conv_dgrad_s1_bf3: stride 1, CO %% 32");
   // full correlation of dY (an [OH,OW,CO] image) with the flipped kernel, padding KH-1-pad
   const ConvDesc dd{d.B, d.OH(), d.OW(), d.CO, d.C, d.KH, d.KW, 1, d.KH - 1 - d.pad, 0};
-  return conv_fwd_bf3(dy_planes, dd, wflip_planes, dx, nullptr, nullptr, nullptr, st, nullptr, nullptr, nullptr);
+  return conv_fwd_bf3(dy_planes, dd, wflip_planes, dx, nullptr, nullptr, tail_ws, st, nullptr, nullptr, nullptr, ACT_NONE,
+                      tail_ws_slabs);
 }
 
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
