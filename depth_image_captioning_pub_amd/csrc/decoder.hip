@@ -235,6 +235,15 @@ struct FusedLstm {
   int nslab, nb_prev, nb_cur, packed_off_prev;
 };
 
+#ifdef DIC_EXPERIMENTS
+// phase time stamps of attn_fwd_kernel (s_memtime, workgroup 0 / a middle workgroup, thread 0): scripts/diag_attn_phases.py
+__device__ unsigned long long g_attn_stamps[2][16];
+#define DIC_ATTN_STAMP(I_)                                                                                   \
+  if (threadIdx.x == 0 && (lin == 0 || lin == 257)) g_attn_stamps[lin == 0 ? 0 : 1][I_] = __builtin_amdgcn_s_memtime();
+#else
+#define DIC_ATTN_STAMP(I_)
+#endif
+
 template <int L>
 __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     const float* __restrict__ F, const float* __restrict__ P, const float* __restrict__ Hall,
@@ -272,6 +281,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   const int l32 = lane & 31, hw = w * 2 + (lane >> 5);
   const bool lstm_only = fl.slab && b >= fl.nb_cur;              // row finished at t-1: only chunk 0 completes its last cell
   if (lstm_only && chunk != 0) return;
+  DIC_ATTN_STAMP(0)
 
   // ---- early load (compact layout): q weights (W_h^T quarter of this wave), in flight together with the LSTM slabs
   float wv[32];
@@ -323,6 +333,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   }
   if (tid >= 256 && tid < 256 + (EP - L)) e_s[L + tid - 256] = 0.f;  // padding cells of the context loop
   __syncthreads();
+  DIC_ATTN_STAMP(1)
   const int dl = tid & 255, half = w >> 2;
   const float* Wg = WbT + (long long)(half * 64) * kD + chunk * 256 + (w & 3) * 64;           // uniform
   const float* Fu = F + (long long)b * L * kD + chunk * 256;                              // uniform
@@ -353,6 +364,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     q_s[quarter][a] = s;
   }
   __syncthreads();
+  DIC_ATTN_STAMP(2)
   if (tid < kA) {
     const float q = b_h[tid] + ((q_s[0][tid] + q_s[1][tid]) + (q_s[2][tid] + q_s[3][tid]));
     q_s[0][tid] = q;
@@ -360,6 +372,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
   }
   if (chunk == 0 && tid < kH && Xall) Xall[bt * kXK + kE + kD + tid] = h_s[tid];   // h_prev slot of the LSTM input
   __syncthreads();
+  DIC_ATTN_STAMP(3)
   {  // e[l] = w . relu(P[l,:] + q) + b : one 32-lane half-wave per cell, float4 per lane, 16 cells per pass
     const float4 q4 = *reinterpret_cast<const float4*>(&q_s[0][l32 * 4]);
     const float4 w4 = *reinterpret_cast<const float4*>(w_full + l32 * 4);
@@ -400,7 +413,9 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
       for (int k = 0; k < 32; ++k) wg[k] = Wg[(long long)(32 + k) * kD + lane];
     }
   }
+  DIC_ATTN_STAMP(4)
   __syncthreads();
+  DIC_ATTN_STAMP(5)
   {  // attention weights over the L cells
     float z = -INFINITY;
     if (tid < L) {
@@ -440,6 +455,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     }
   }
   __syncthreads();
+  DIC_ATTN_STAMP(6)
   {  // ctx[d] = sum_l alpha[l] F[b,l,d] over this chunk (two batches of NB cells per wave), fused with the pre-activation of
      // gate = sigmoid(W_beta h + b) for the same 256 channels (two halves of K per channel)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -484,7 +500,9 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
     *reinterpret_cast<float4*>(&cred[w][lane * 4]) = acc;
     gp_s[half][dl] = gs;
   }
+  DIC_ATTN_STAMP(7)
   __syncthreads();
+  DIC_ATTN_STAMP(8)
   if (tid < 256) {  // x = gate * ctx          (depth_models.py:189-190)
     const int d = chunk * 256 + tid;
     const float c = ((cred[0][tid] + cred[1][tid]) + (cred[2][tid] + cred[3][tid])) +
@@ -496,6 +514,7 @@ __global__ void __launch_bounds__(512, 4) attn_fwd_kernel(
       Xall[bt * kXK + kE + d] = g * c;
     }
   }
+  DIC_ATTN_STAMP(9)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1575,3 +1594,11 @@ int dic_attention_bwd(const float* enc_att_w, const float* enc_att_b, const floa
 }
 
 }  // extern "C"
+
+#ifdef DIC_EXPERIMENTS
+/* development aid (not in dic.h): the phase time stamps of the most recent attn_fwd_kernel launch (2 workgroups x 16 stamps) */
+extern "C" int dic_debug_attn_stamps(unsigned long long* host32) {
+  DIC_CHECK_HIP(hipMemcpyFromSymbol(host32, HIP_SYMBOL(dic::g_attn_stamps), sizeof(unsigned long long) * 32));
+  return 0;
+}
+#endif
