@@ -87,6 +87,20 @@ def test_two_rank_step_equals_one_rank_emulation(lib, tmp_path, full_size, monke
     assert err <= 1e-5, f"2-rank parameters differ from the 1-rank emulation by {err:.3e}"
 
 
+def test_bench_hard_workload_line(lib):
+    """`bench.py --hard` (the depth-hard step of BASELINE config 4 as a separate workload line, never the headline): runs, names
+    itself, streams all 196 cells, and its same-run parity gate (CPU oracle's depth-hard step on the same Gumbel draws) is green."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--hard", "--steps", "3", "--warmup", "2", "--batch", "16", "--no-alt-mode",
+           "--cpu-batch", "8", "--cpu-iters", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert "depth-hard" in d["metric"] and "Gumbel" in d["config"]["workload"] and d["config"]["annotation_cells"] == 196
+    assert d["value"] > 0 and d["parity"]["ok"] and d["parity"]["annotation_cells"] == 196
+    assert "depth-hard" in d["cpu_baseline"]["sample"]
+
+
 def test_rccl_entry_points_of_the_c_abi_single_rank(lib):
     """dic_comm_unique_id / dic_comm_create / dic_allreduce_grads / dic_comm_destroy (include/dic.h, "data parallel"): the
     gradient exchange for callers that bind the C ABI without torch.distributed.  A one-GPU box admits one RCCL rank per
