@@ -101,6 +101,17 @@ def test_bench_hard_workload_line(lib):
     assert "depth-hard" in d["cpu_baseline"]["sample"]
 
 
+def test_engine_exchange_over_rccl_single_rank(lib):
+    """engine.exchange_gradients over a real RCCL process group (`torch.distributed` backend "nccl", one rank on cuda:0): the
+    collective code path of the data-parallel step executes on RCCL here - with one rank, which is all a one-GPU box admits;
+    the N-rank behaviour is covered over gloo (two ranks sharing this GPU, and world 2 / 4 on the CPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_rccl_worker.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_EXCHANGE_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_rccl_entry_points_of_the_c_abi_single_rank(lib):
     """dic_comm_unique_id / dic_comm_create / dic_allreduce_grads / dic_comm_destroy (include/dic.h, "data parallel"): the
     gradient exchange for callers that bind the C ABI without torch.distributed.  A one-GPU box admits one RCCL rank per
