@@ -4,9 +4,10 @@
 
 using namespace dic;
 
-namespace dic { void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); }
+namespace dic { void resnet_fuse_bn_operand(int mask); void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n); }
 #ifdef DIC_EXPERIMENTS
-namespace dic { void decoder_debug_persistent(int on); void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p); }
+namespace dic { void decoder_debug_persistent(int on); void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p);
+                void resnet_debug_skip_bn_apply(int on); }
 #endif
 
 extern "C" {
@@ -43,11 +44,13 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
  * kernels side by side; every other code (ablations, parked kernels) exists only in the experiments build. */
 int dic_debug_force_staged_gemm(int on) {
   if (gemm_bf3_force_tile(on) == 0) return 0;
+  if (on >= 100 && on <= 103) { dic::resnet_fuse_bn_operand(on - 100); return 0; }
 #ifdef DIC_EXPERIMENTS
   if (on == 140 || on == 141) { dic::decoder_debug_persistent(on - 140); return 0; }          // decoder forward: per-step launches / persistent loop
   if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement
   if (on >= 130 && on <= 134) { dic::conv1_depth_debug_blocks(256 * (on - 130)); return 0; }   // generic path / 256 / 512 / 768 / 1024 workgroups
   if (on >= 120 && on <= 123) { dic::resnet_debug_fused_tail_bn(on - 120); return 0; }
+  if (on >= 124 && on <= 127) { dic::resnet_debug_skip_bn_apply(on == 125 ? 3 : on == 126 ? 2 : on == 127 ? 1 : 0); return 0; }   // (measurement only) bn_apply_planes: run / skip all / skip block outputs / skip c1, c2 outputs
   if (on >= 0 && on <= 13) { gemm_force_v1(on); return 0; }
 #endif
   DIC_REQUIRE(false, "debug switch: unknown code %d", on);
@@ -79,6 +82,14 @@ int dic_debug_conv_bf3(const uint16_t* const x_planes[3], int B, int H, int W, i
 int dic_conv_persistent_grid(int max_workgroups) {
   DIC_REQUIRE(gemm_bf3_set_persist_grid(max_workgroups) == 0, "dic_conv_persistent_grid: 1 <= max_workgroups <= 1024");
   return DIC_OK;
+}
+/* development aid (not in dic.h): the 1x1 convolution with on-the-fly BatchNorm / residual / ReLU / split of its input
+ * (conv1x1_fwd_bf3_bn, gemm_bf3.hip); returns 1 when the policy would not run the shape on the persistent kernel */
+int dic_debug_conv1x1_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out, int M,
+                         int C, const uint16_t* const w_planes[3], int CO, float* y, float* bn_partial, int* mtiles_out, float* tail_ws,
+                         int tail_ws_slabs, void* stream) {
+  return conv1x1_fwd_bf3_bn(raw, scale, shift, res, relu, act_out, M, C, w_planes, CO, y, bn_partial, mtiles_out, tail_ws, tail_ws_slabs,
+                            (hipStream_t)stream, nullptr, nullptr);
 }
 int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {

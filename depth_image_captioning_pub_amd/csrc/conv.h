@@ -28,6 +28,12 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st,
                  const float* bias = nullptr, const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr,
                  int act = 0 /* ACT_NONE */, int tail_ws_slabs = 256 /* [64][64]-float slabs in tail_ws (kGemmTailWsBytes = 256) */);
+// 1x1 convolution with the BatchNorm-apply (+ residual) + ReLU + split of its input fused into the operand path (gemm_bf3.hip);
+// returns 1 (nothing launched) when the shape would not run on the persistent warp-specialised kernel
+int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
+                       int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
+                       int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse = nullptr,
+                       int* bn_fused = nullptr);
 constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a larger tail region: every CU can take a remainder piece
 // bn_fuse: when the launch is tail-split, finalize the train-mode BatchNorm inside the fix-up launch (*bn_fused = 1)
 // data gradient of a stride-1 convolution through the same kernel: dy planes [B,OH,OW,CO], flipped weights

@@ -167,13 +167,14 @@ static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
 }
 
 struct RnWs {
-  float* act[4];
+  float* act[6];                    // raw conv outputs (conv1, conv2, conv3, downsample) + two fp32 block-input buffers (bf16x3 mode)
   unsigned short* planes[3][3];     // bf16x3 mode: three rotating activation buffers x (hi, mid, lo)
   unsigned short* stem_planes[3];   // bf16x3 mode: zero-padded NHWC4 image planes of the stem (conv_stem_bf3)
   float* partial;
   float* tail;
   double* red;
   BnBuf bn;
+  BnBuf bn2, bn3;                   // bf16x3 mode: conv2 / conv3 statistics (conv3's outlive the block: the next block's conv1 applies them)
   BnBuf bn_ds;                      // statistics of the downsample branch (applied inside the block's last BN pass)
   size_t bytes;
 };
@@ -181,7 +182,7 @@ struct RnWs {
 static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov) {
   Carver c(p, bytes);
   RnWs w{};
-  for (int i = 0; i < 4; ++i) w.act[i] = c.take<float>(pl.max_act);
+  for (int i = 0; i < (mode == 1 ? 6 : 4); ++i) w.act[i] = c.take<float>(pl.max_act);
   if (mode == 1)
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) w.planes[i][j] = c.take<unsigned short>(pl.max_act + 2048);   // + one pad row (paired layout)
@@ -191,6 +192,8 @@ static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov
   w.red = c.take<double>(pl.max_red);
   w.tail = c.take<float>(std::max((size_t)kResnetTailSlabs * 64 * 64, kGemmTailWsBytes / sizeof(float)));
   w.bn = take_bn(c, 2048);
+  w.bn2 = take_bn(c, 2048);
+  w.bn3 = take_bn(c, 2048);
   w.bn_ds = take_bn(c, 2048);
   w.bytes = c.off;
   if (ov) *ov = c.overflow;
@@ -207,6 +210,16 @@ static int conv_bn(const float* x, const ConvDesc& d, const dic_conv_bn_layer& L
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
+#ifdef DIC_EXPERIMENTS
+static int g_skip_bn_apply = 0;     // measurement only (codes 124..127): bit 0 = skip the bn_apply_planes launches of c1 / c2 outputs, bit 1 = of block outputs (results
+                                    // are then those of stale planes - timing experiment "does the pass ride for free next to other forwards")
+void resnet_debug_skip_bn_apply(int on) { g_skip_bn_apply = on; }
+#define DIC_BN_APPLY_PLANES(...) do { if (!(g_skip_bn_apply & 1)) DIC_TRY(bn_apply_planes(__VA_ARGS__)); } while (0)       /* c1 / c2 outputs */
+#define DIC_BN_APPLY_PLANES_OUT(...) do { if (!(g_skip_bn_apply & 2)) DIC_TRY(bn_apply_planes(__VA_ARGS__)); } while (0)   /* block outputs */
+#else
+#define DIC_BN_APPLY_PLANES(...) DIC_TRY(bn_apply_planes(__VA_ARGS__))
+#define DIC_BN_APPLY_PLANES_OUT(...) DIC_TRY(bn_apply_planes(__VA_ARGS__))
+#endif
 static int g_strip_stem = 1;        // benchmarking (codes 122/123): 0 = stem on the exact-fp32 gather kernel
 static int g_fused_tail_bn = 1;     // benchmarking (codes 120/121): 0 = separate tail fix-up and BN finalize launches
 void resnet_debug_fused_tail_bn(int on) { if (on >= 2) g_strip_stem = on - 2; else g_fused_tail_bn = on; }
@@ -230,12 +243,44 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
-// ResNet forward with the bf16x3 convolution: every activation that feeds a convolution is kept as three bf16 planes
-// (written by the BatchNorm-apply kernels), block outputs additionally in fp32 for the residual connection.
+// conv1x1 whose input is act(raw * in_bn.scale + in_bn.shift (+ res)) formed inside the kernel's producer waves (conv1x1_fwd_bf3_bn,
+// gemm_bf3.hip) -> raw fp32 out + BN scale/shift in `bn`.  Returns 1 when the launch policy keeps the shape off that kernel (nothing
+// launched, nothing written).
+static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* res, float* act_out, const ConvDesc& d,
+                             const dic_conv_bn_layer& L, float* y, const RnWs& ws, int train_bn, hipStream_t st, const BnBuf& bn) {
+  if (!(d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && d.C <= 2048)) return 1;
+  int mtiles = 0, fused = 0;
+  const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
+  const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
+                      (double)d.M(), kBnEps, kBnMomentum};
+  const int rc = conv1x1_fwd_bf3_bn(raw, in_bn.scale, in_bn.shift, res, 1, act_out, d.M(), d.C, wp, d.CO, y, train_bn ? ws.partial : nullptr,
+                                    &mtiles, ws.tail, kResnetTailSlabs, st, (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused);
+  if (rc != DIC_OK) return rc;
+  if (train_bn && fused) return DIC_OK;
+  if (train_bn)
+    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, ws.red, st);
+  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+}
+
+// which BatchNorm-apply passes are folded into the consuming 1x1 convolution (codes 100..103 of dic_debug_force_staged_gemm):
+// bit 0 = the block output (relu(bn3(conv3) + identity), consumed by the next block's conv1), bit 1 = conv2's output (consumed by conv3)
+static int g_fuse_bn_operand = 3;
+void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand = mask & 3; }
+
+// ResNet forward with the bf16x3 convolution.  A convolution reads either three bf16 planes (written by a bn_apply_planes pass; the 3x3
+// and strided layers need that form) or - the stride-1 1x1 layers on the persistent kernel - the raw fp32 output of the layer before
+// it, normalised / residual-added / rectified / split on the way into LDS (no pass, no planes in HBM).  Inside a stage that makes
+//   conv1 (b >= 1): relu(bn3(raw3 of block b-1) + identity of block b-1) formed on the fly; the same kernel writes that block input
+//                   once as fp32 (it is the identity of block b)
+//   conv2 (3x3):    planes of relu(bn1(raw1))                    (one pass over M x planes)
+//   conv3:          relu(bn2(raw2)) on the fly
+// and only the last block of a stage materialises its output as planes (the next stage's strided downsample conv reads them).
 static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, const float* imgs_nchw, int B, int train_bn,
                           float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st, int pool_out) {
   size_t ci = 0;
-  float *X = ws.act[0], *A = ws.act[1], *Bf = ws.act[2], *Cf = ws.act[3];
+  float *R2 = ws.act[0], *R3 = ws.act[1], *R1 = ws.act[2], *Cf = ws.act[3];
+  float* const IN[2] = {ws.act[4], ws.act[5]};
+  float* const X = ws.act[0];             // fp32 copy of the final map for the pooling (R2 is dead by then)
   unsigned short* const* Xp = ws.planes[0];
   unsigned short* const* P1 = ws.planes[1];
   unsigned short* const* P2 = ws.planes[2];
@@ -246,45 +291,73 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       // strip formulation on the bf16x3 kernel (w_hi/mid/lo of layer 0 = dic_resnet_pack_stem_weights)
       int mtiles = 0;
       const unsigned short* wp[3] = {L0.w_hi, L0.w_mid, L0.w_lo};
-      DIC_TRY(conv_stem_bf3(imgs_nchw, B, c.d.H, c.d.W, 64, ws.stem_planes, wp, A, train_bn ? ws.partial : nullptr, &mtiles, st));
+      DIC_TRY(conv_stem_bf3(imgs_nchw, B, c.d.H, c.d.W, 64, ws.stem_planes, wp, R3, train_bn ? ws.partial : nullptr, &mtiles, st));
       if (train_bn)
         DIC_TRY(bn_finalize_train(ws.partial, mtiles, c.d.M(), 64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn,
                                   ws.red, st));
       else
         DIC_TRY(bn_finalize_eval(64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn, st));
     } else
-    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], A, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
+    DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], R3, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
     // BN + ReLU + maxpool straight into the planes of the first bottleneck's input (no fp32 copy, no split pass)
-    DIC_TRY(bn_relu_maxpool(A, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, nullptr, nullptr, st, Xp));
+    DIC_TRY(bn_relu_maxpool(R3, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, nullptr, nullptr, st, Xp));
   }
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < 4; ++s) {
+    bool pending = false;                  // the block input is not materialised: it is relu(bn3(R3) + pend_res)
+    const float* pend_res = nullptr;
     for (int b = 0; b < blocks[s]; ++b) {
       const RnConv& c1 = pl.convs[ci++];
       const RnConv& c2 = pl.convs[ci++];
       const RnConv& c3 = pl.convs[ci++];
-      DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], A, ws, train_bn, st));
-      DIC_TRY(bn_apply_planes(A, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st));
-      DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], Bf, ws, train_bn, st));
-      DIC_TRY(bn_apply_planes(Bf, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn, 1, st));
-      // identity: the block input, which exists only as planes ((hi + mid) + lo is the fp32 value exactly), or the
-      // fp32 output of the downsample branch in the first block of a stage
-      const float* identity = nullptr;
+      const float* in32 = nullptr;         // the block input as fp32, when it exists (else it exists as planes Xp)
+      if (pending) {
+        float* in_b = IN[b & 1];
+        int rc = conv_bn_bf3_fused(R3, ws.bn3, pend_res, in_b, c1.d, layers[c1.layer], R1, ws, train_bn, st, ws.bn);
+        if (rc == 1) {                      // shape not on the persistent kernel: form the input as planes (+ fp32) after all
+          DIC_BN_APPLY_PLANES_OUT(R3, pend_res, nullptr, in_b, Xp, c1.d.M(), c1.d.C, ws.bn3, 1, st);
+          rc = conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st);
+        }
+        DIC_TRY(rc);
+        in32 = in_b;
+      } else {
+        DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st));
+      }
+      DIC_BN_APPLY_PLANES(R1, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st);
+      DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], R2, ws, train_bn, st, &ws.bn2));
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
         // downsample branch: raw output + its own statistics; its BatchNorm is applied where the block output is formed
         DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st, &ws.bn_ds));
-        identity = Cf;
       }
-      DIC_TRY(conv_bn_bf3(P2, c3.d, layers[c3.layer], A, ws, train_bn, st));
-      // out = relu(bn3 + identity) as planes (next conv input / next identity) into P1 (free again); only the very last
-      // block also writes fp32, for the pooling that follows
+      {
+        int rc = (g_fuse_bn_operand & 2) ? conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3)
+                                         : 1;
+        if (rc == 1) {
+          DIC_BN_APPLY_PLANES(R2, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn2, 1, st);
+          rc = conv_bn_bf3(P2, c3.d, layers[c3.layer], R3, ws, train_bn, st, &ws.bn3);
+        }
+        DIC_TRY(rc);
+      }
+      // block output relu(bn3(R3) + identity); identity = the block input (planes Xp, or fp32 when conv1 formed it) or, in the first
+      // block of a stage, the downsample branch
       const bool last = (s == 3 && b == blocks[s] - 1);
+      if ((g_fuse_bn_operand & 1) && b + 1 < blocks[s] && (b == 0 || in32)) {
+        // left to the next block's conv1.  The downsample output is normalised in place first (the kernel adds a plain residual)
+        if (b == 0) DIC_TRY(bn_apply(Cf, nullptr, Cf, c3.d.M(), c3.d.CO, ws.bn_ds, 0, st));
+        pend_res = b == 0 ? Cf : in32;
+        pending = true;
+        continue;
+      }
+      pending = false;
+      const float* identity = b == 0 ? Cf : in32;
       const unsigned short* idp[3] = {Xp[0], Xp[1], Xp[2]};
+      // planes into P1 (free again); only the very last block also writes fp32, for the pooling that follows
       // (pool_out == 0: the final map itself is the output, written in place of the fp32 copy)
-      DIC_TRY(bn_apply_planes(A, identity, identity ? nullptr : idp, last ? (pool_out == 0 ? features : X) : nullptr, P1, c3.d.M(), c3.d.CO, ws.bn, 1,
-                              st, identity ? &ws.bn_ds : nullptr));
+      DIC_BN_APPLY_PLANES_OUT(R3, identity, identity ? nullptr : idp, last ? (pool_out == 0 ? features : X) : nullptr, P1, c3.d.M(), c3.d.CO,
+                              ws.bn3, 1, st, b == 0 ? &ws.bn_ds : nullptr);
       std::swap(Xp, P1);
     }
+  }
   if (pool_out == 0) return DIC_OK;       // features already hold the [B, outH*outW, 2048] map
   return adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, pool_out, features, st);
 }

@@ -77,7 +77,16 @@ struct Bf3Params {
   float* ws;
   int tail_first_block, tail_first_tile, tail_split;   // remainder-tile K split, as in gemm.hip (64x64 tile only)
   float* tail_ws;
+  // A operand computed on the fly (OPK_ROWK_BN, warp-specialised kernel only): A(m,k) = act(a_raw[m][k] * a_scale[k] + a_shift[k]
+  // (+ a_res[m][k])) - the BatchNorm-apply / residual / ReLU pass that would otherwise write it as planes; a_out (nullable)
+  // receives the fp32 values once (tiles with tn == 0): the block output that is the next block's identity
+  const float *a_raw, *a_scale, *a_shift, *a_res;
+  float* a_out;
+  long long a_ld;
+  int a_relu;
 };
+constexpr int OPK_ROWK_BN = 6;     // (A-operand kind of the kernel template; never stored in Bf3Operand::kind)
+constexpr int kBnTabMax = 2048;    // channels of the on-the-fly operand (its scale / shift table lives in LDS)
 
 // One operand's DMA bookkeeping: a wave-instruction fills 16 rows x 64 B of one plane image; wave w takes the row
 // groups w, w+4, ... of each of the three planes.  Address arithmetic is done once per output tile.
@@ -363,6 +372,8 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   constexpr int BM = 128, BN = 128;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];
+  constexpr bool kBn = AK == OPK_ROWK_BN;
+  __shared__ float bn_tab[kBn ? 2 * kBnTabMax : 1];      // scale | shift of the on-the-fly operand (144 + 16 KB = all of the LDS)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = (p.K + BK3 - 1) / BK3;
@@ -383,7 +394,212 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   const int nwork = ntl + (has_piece ? 1 : 0);
   const int total = ntl * nkt + npk;
   if (total == 0) return;
+  if constexpr (kBn) {     // scale / shift of every input channel -> LDS (all eight waves; one barrier, once per launch)
+    for (int k = tid; k < p.K; k += 512) { bn_tab[k] = p.a_scale[k]; bn_tab[kBnTabMax + k] = p.a_shift[k]; }
+    __syncthreads();
+  }
 
+  if constexpr (kBn) {
+  if (wave >= 4) {
+    // ---------------- producer waves, on-the-fly A operand.  B tiles: LDS-DMA three slots ahead, as in the plain kernel.  A tiles:
+    // every thread loads 16 raw fp32 values (and residuals) of the 128 x 32 tile into registers two slots ahead,
+    // and one slot ahead of the consumers turns them into act(raw * scale + shift (+ residual)), splits them into the three
+    // bf16 planes (v_cvt_pk_bf16_f32: the same round-to-nearest-even as split3_bf16) and writes the swizzled LDS image the
+    // DMA would have produced.  Slot s lives in register set s % DA.
+    //   iteration g:  wait L(g+1), D(g+1)  ->  transform slot g+1 into stage (g+1) % 3 [+ store the fp32 values]  ->  barrier g
+    //                 ->  D(g+3) into stage g % 3,  L(g+1+DA) into the register set just freed
+    // (a load has DA - 1 K-tile periods to arrive: with two sets the kernel ran at the memory latency, 2.5 us per K tile)
+    // Thread mapping of the 128 x 32 fp32 tile: a wave instruction reads 8 rows x 128 B (8 lanes x 16 B per row: whole cache
+    // lines, every byte used once); thread (r8, kq) of producer wave pw holds channels 4*kq..4*kq+3 of rows pw*32 + 8*i + r8.
+    const int pt = tid - 256, prow0 = (pt >> 6) * 32 + ((pt & 63) >> 3), kq = pt & 7;
+    __builtin_amdgcn_s_setprio(3);       // the transform's vector instructions go ahead of the computing wave of the same SIMD
+    const bool has_res = p.a_res != nullptr;
+    Bf3Loader<OPK_ROWK, BN> lbld;
+    // ---- slot iterators: (work item, K tile) of the next B slot to issue / next A slot to load / next A slot to transform
+    struct It { int j, kt, k0, nk; };
+    auto it_init = [&](It& it) { it.j = 0; it.kt = 0; it.k0 = ntl > 0 ? 0 : pk0; it.nk = ntl > 0 ? nkt : npk; };
+    auto it_tile = [&](const It& it) { return it.j < ntl ? xcd_remap(blockIdx.x + it.j * G, F) : piece_tile; };
+    auto it_next = [&](It& it) {          // returns true when it moved on to the next work item
+      if (++it.kt < it.nk) return false;
+      it.kt = 0; ++it.j;
+      const bool whole = it.j < ntl;
+      it.k0 = whole ? 0 : pk0; it.nk = whole ? nkt : npk;
+      return true;
+    };
+    It itb, itl;
+    it_init(itb); it_init(itl);
+    { const int t = it_tile(itb); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); }
+    auto issue_b = [&](unsigned short* stage) {
+      lbld.issue((itb.k0 + itb.kt) * BK3, stage + AOPER);
+      if (it_next(itb) && itb.j < nwork) { const int t = it_tile(itb); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); }
+    };
+    // register set of one slot (DA instances; indices are compile-time constants after unrolling: no runtime-indexed register arrays)
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    struct ASet {
+      f32x4_ ra[4], rr[4];                // raw values, residuals (row prow0 + 8 * i)
+      unsigned off0;                      // byte offset of the thread's first row in a_raw / a_res / a_out
+      unsigned tab;                       // byte offset of the thread's first channel in the scale / shift table
+      unsigned flg;                       // bits 0..3: row i inside the matrix, bit 4: this tile stores a_out, bit 5: ragged tile (wave-uniform)
+    };
+    constexpr int DA = 4;                 // A slots in flight (register sets); slot s lives in set s % DA
+    ASet sets[DA];
+    if (!has_res) {                       // the residual registers stay zero for the whole launch (the transform always adds them)
+#pragma unroll
+      for (int d = 0; d < DA; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sets[d].rr[i] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    }
+    // loader state of the tile `itl` is in: 32-bit byte offsets (the host checks M * ld * 4 < 2^32) of the thread's four rows
+    // (clamped to the last row of the matrix) at channel 4 * kq, and the flags every slot of the tile carries
+    const unsigned ldb = (unsigned)p.a_ld * 4u;
+    unsigned lrow[4], lrow0 = 0, lflg = 0;
+    auto load_tile = [&]() {
+      const int t = it_tile(itl), tm = t / p.ntiles, tn = t - tm * p.ntiles;
+      const int gr = tm * BM + prow0;
+      lrow0 = (unsigned)gr * ldb + (unsigned)kq * 16u;
+      lflg = ((tn == 0 && p.a_out != nullptr) ? 16u : 0u) | ((tm * BM + BM > p.M) ? 32u : 0u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lflg |= (gr + 8 * i < p.M) ? (1u << i) : 0u;
+        lrow[i] = (unsigned)min(gr + 8 * i, p.M - 1) * ldb + (unsigned)kq * 16u;
+      }
+    };
+    load_tile();
+    auto load_a = [&](ASet& S) {          // L(s): the slot at `itl`
+      const unsigned kb = (unsigned)(itl.k0 + itl.kt) * (BK3 * 4u);
+      S.off0 = lrow0 + kb; S.tab = kb + (unsigned)kq * 16u; S.flg = lflg;
+      // (inline asm: a load the compiler can see gets a compiler-placed vmcnt(0) at its first use - it cannot count across this
+      //  control flow - which drains every slot in flight; the counted waits below are followed by a statement naming the registers)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned vo = lrow[i] + kb;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.ra[i]) : "v"(vo), "s"(p.a_raw) : "memory");
+      }
+      if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned vo = lrow[i] + kb;
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.rr[i]) : "v"(vo), "s"(p.a_res) : "memory");
+        }
+      }
+      if (it_next(itl) && itl.j < nwork) load_tile();
+    };
+    // LDS image: row r of a plane is 64 B (32 bf16); its 16-B chunk c sits at position c ^ ((r >> 2) & 3); the thread's 4 values
+    // are the 8-B half (kq & 1) of chunk kq >> 1
+    unsigned doff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned r = (unsigned)(prow0 + 8 * i);
+      doff[i] = r * 64u + ((((unsigned)kq >> 1) ^ ((r >> 2) & 3u)) << 4) + ((unsigned)kq & 1u) * 8u;
+    }
+    const float relu_floor = p.a_relu ? 0.f : -__builtin_inff();
+    auto transform = [&](ASet& S, unsigned short* stage) {      // T(s): registers -> three plane images of the stage
+      // (LDS accesses of the producer waves are inline asm with their own lgkmcnt waits: hipcc would otherwise drain every
+      //  LDS-DMA in flight - vmcnt(0) - before an LDS access it can see)
+      u32x4 scq, shq;
+      const unsigned tab = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)bn_tab + S.tab;
+      bf3_lds_read(scq, tab); bf3_lds_read(shq, tab + (unsigned)kBnTabMax * 4u);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(scq), "+v"(shq)::"memory");
+      const float4 s4 = __builtin_bit_cast(float4, scq), t4 = __builtin_bit_cast(float4, shq);
+      const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)stage;
+      typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      float v[4][4];
+      const f32x2_ s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w}, t01 = {t4.x, t4.y}, t23 = {t4.z, t4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4_ x = S.ra[i], q = S.rr[i];
+        const f32x2_ a01 = f32x2_{x.x, x.y} * s01 + t01 + f32x2_{q.x, q.y}, a23 = f32x2_{x.z, x.w} * s23 + t23 + f32x2_{q.z, q.w};    // packed fp32 fma / add
+        v[i][0] = fmaxf(a01.x, relu_floor); v[i][1] = fmaxf(a01.y, relu_floor);
+        v[i][2] = fmaxf(a23.x, relu_floor); v[i][3] = fmaxf(a23.y, relu_floor);
+      }
+      if (__builtin_amdgcn_readfirstlane(S.flg) & 32u) {        // last M tile of a ragged matrix: rows past the end are zero
+        asm volatile("" ::: "memory");                           // (keeps this a branch: 16 selects per slot otherwise)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!((S.flg >> i) & 1u)) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((S.flg & 16u) && ((S.flg >> i) & 1u))
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.a_out) + (size_t)(S.off0 + (unsigned)(8 * i) * ldb)) =
+              make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        u32x2_ qh, qm, ql;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x2_ xx = {v[i][2 * u], v[i][2 * u + 1]};
+          const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, bfx2));
+          const f32x2_ r1 = {xx.x - __uint_as_float(hb << 16), xx.y - __uint_as_float(hb & 0xffff0000u)};
+          const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bfx2));
+          const f32x2_ r2 = {r1.x - __uint_as_float(mb << 16), r1.y - __uint_as_float(mb & 0xffff0000u)};
+          qh[u] = hb; qm[u] = mb; ql[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bfx2));
+        }
+        const unsigned dst = sbase + doff[i];
+        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(qh) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(qm), "i"(APLANE * 2) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(ql), "i"(2 * APLANE * 2) : "memory");
+      }
+    };
+    // ---- prologue: B slots 0..2 and A slots 0..DA-1 in flight; slot 0 transformed; then A slot DA
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0)
+      if (s0 < total) issue_b(smem + s0 * STAGE);
+#pragma unroll
+    for (int s0 = 0; s0 < DA; ++s0)
+      if (s0 < total) load_a(sets[s0]);
+    const bool steady_ok = total >= 2 * DA + 2;                    // shorter streams: plain vmcnt(0) waits
+    // (s_waitcnt takes an immediate: the few counts that occur are spelled out; a smaller count than necessary is always safe)
+    // the counted wait (one of a few immediates, picked by scalar branches), then ONE statement that names the registers of the
+    // slot just released: every use of them is ordered behind it.  (A wait with the registers as operands in each branch arm
+    // made the compiler copy the whole set - before the wait, i.e. before the data had arrived.)
+#define DIC_PIN_SLOT(S_)                                                                                                          \
+  asm volatile("" : "+v"((S_).ra[0]), "+v"((S_).ra[1]), "+v"((S_).ra[2]), "+v"((S_).ra[3]), "+v"((S_).rr[0]), "+v"((S_).rr[1]),   \
+               "+v"((S_).rr[2]), "+v"((S_).rr[3]) :: "memory")
+    auto wait_early = [&]() {            // at most (DA - 1) * nl outstanding
+      if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 8) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 4) : "memory");
+    };
+    auto wait_steady = [&]() {           // at most (DA - 1) * (6 + nl) outstanding
+      if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 14) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 10) : "memory");
+    };
+    if (steady_ok) wait_early(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DIC_PIN_SLOT(sets[0]);
+    transform(sets[0], smem);
+    if (DA < total) load_a(sets[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
+    int st = 0;
+    for (int g0 = 0; g0 < total; g0 += DA) {
+#pragma unroll
+      for (int u = 0; u < DA; ++u) {
+        const int g = g0 + u;
+        if (g >= total) break;
+        const int stn = st == NST - 1 ? 0 : st + 1;
+        if (g + 1 < total) {
+          // L(g+1) done.  Younger in issue order: iterations g-DA+1 .. g-1 each issued D(j+3) (6) and L(j+1+DA) (nl) [and, in tiles that
+          // store, 4 stores - not counted: the wait then also covers stores that are DA-1 iterations old]; in the first DA-1
+          // iterations the prologue's loads take the place of the missing iterations; near the end of the stream, where slots
+          // are no longer issued, wait for everything.
+          // ((DA-1-g) * nl + g * (6 + nl) there; the prologue's count (DA-1) * nl is below all of them)
+          if (!(steady_ok && g + DA < total)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (g >= DA - 1) wait_steady();
+          else wait_early();
+          DIC_PIN_SLOT(sets[(u + 1) % DA]);
+          transform(sets[(u + 1) % DA], smem + stn * STAGE);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                              // slot g+1 is in LDS; the consumers are done with stage st
+        if (g + NST < total) issue_b(smem + st * STAGE);
+        if (g + 1 + DA < total) load_a(sets[(u + 1) % DA]);
+        st = stn;
+      }
+    }
+#undef DIC_PIN_SLOT
+    return;
+  }
+  } else
   if (wave >= 4) {
     // ---------------- producer waves: slot g of the stream goes to ring stage g % NST
     Bf3Loader<AK, BM> la;
@@ -1007,11 +1223,14 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       }
     }
   }
+  if (p.a_raw && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) return 1;      // on-the-fly operand: persistent 1x1 kernel or nothing
   gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
   if (persist && (halo || !ws256) && (halo || g_bf3_ws) && g_bf3_ablate == 0) {      // the product's 128x128 kernels
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
     const int grid = persist_grid;
+    if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN>), dim3(grid), dim3(512), 0, st, p);
+    else
     if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<0>, dim3(grid), dim3(512), 0, st, p);
     else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
@@ -1091,6 +1310,31 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.ep.stats = bn_partial;
   if (bn_fused) *bn_fused = 0;
   DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs));
+  if (mtiles_out) *mtiles_out = g_last_mtiles;
+  return DIC_OK;
+}
+
+// 1x1 convolution whose input is formed on the fly: y_raw[M][CO] = act(raw[M][C] * scale[C] + shift[C] (+ res[M][C])) . W^T,
+// i.e. the BatchNorm-apply (+ residual) + ReLU + three-plane split of the input happens in the producer waves of the
+// persistent warp-specialised kernel instead of in a bn_apply_planes pass (20 B per element of HBM traffic and a launch less).
+// act_out (nullable) receives the fp32 input values once.  Returns DIC_OK, 1 when the launch policy would not run this shape on
+// that kernel (nothing launched: the caller takes the bn_apply_planes route), or a negative error.
+int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
+                       int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
+                       int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused) {
+  DIC_REQUIRE(raw && scale && shift && y && C % 32 == 0 && C <= kBnTabMax, "conv1x1_fwd_bf3_bn: C %% 32 == 0, C <= 2048");
+  if ((long long)M * C * 4 >= (1ll << 32)) return 1;        // the kernel addresses the input with 32-bit byte offsets
+  Bf3Params p{};
+  p.M = M; p.N = CO; p.K = C;
+  for (int i = 0; i < 3; ++i) { p.A.p[i] = nullptr; p.B.p[i] = w_planes[i]; }
+  p.A.kind = OPK_ROWK; p.A.ld = C; p.A.paired = 1;
+  p.B.kind = OPK_ROWK; p.B.ld = C; p.B.paired = 1;
+  p.a_raw = raw; p.a_scale = scale; p.a_shift = shift; p.a_res = res; p.a_out = act_out; p.a_ld = C; p.a_relu = relu;
+  p.ep = ep_store(y, CO, nullptr, ACT_NONE);
+  p.ep.stats = bn_partial;
+  if (bn_fused) *bn_fused = 0;
+  const int rc = launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs);
+  if (rc != DIC_OK) return rc;
   if (mtiles_out) *mtiles_out = g_last_mtiles;
   return DIC_OK;
 }

@@ -358,6 +358,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
  *   76           accepted, no effect (the persistent kernel's only form here is the warp-specialised one)
  *   90 91        remainder-round K split of the persistent kernels: off / on (default)
+ *   100..103     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
+ *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both (default)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
  * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes

@@ -14,8 +14,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--conv-mode", default="bf16x3")
+ap.add_argument("--switches", default="", help="comma-separated dic_debug_force_staged_gemm codes")
 a = ap.parse_args()
 DEV = "cuda:0"
+for code in filter(None, a.switches.split(",")):
+    assert native._lib.load().dic_debug_force_staged_gemm(int(code)) == 0, code
 rn = {k: v.to(DEV) for k, v in syn.resnet152_weights(seed=125).items()}
 runner = native.ResNetRunner(rn, conv_mode=a.conv_mode)
 imgs = syn.rgb_images(a.batch, seed=123).to(DEV)

@@ -376,3 +376,75 @@ def test_persistent_kernels_remainder_round_k_split(lib, k):
         yd = res[c][0].double().cpu()
         assert torch.allclose(res[c][1][0], yd.sum(0), rtol=1e-5, atol=1e-4 * scale), c
         assert torch.allclose(res[c][1][1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * scale), c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Cin,CO,res,relu", [(12544, 1024, 256, True, 1), (12544, 256, 1024, False, 1), (12500, 512, 256, True, 0),
+                                               (50176, 512, 128, False, 1), (200704, 64, 256, True, 1)])
+def test_conv1x1_with_on_the_fly_bn_operand(lib, M, Cin, CO, res, relu):
+    """conv1x1_fwd_bf3_bn (csrc/gemm_bf3.hip): the persistent warp-specialised kernel whose producer waves form the A operand
+    on the fly - act(raw * scale + shift (+ residual)), ReLU, exact three-plane bf16 split - instead of reading planes that a
+    bn_apply_planes pass wrote.  Against the two-step route (torch for the elementwise part, dic_split_bf16x3_paired,
+    dic_debug_conv_bf3) and an fp64 evaluation: ResNet layer-3 shapes (conv1 with residual, conv3 = 784 tiles with remainder
+    pieces), a ragged last tile, a short-K layer-1 shape; the materialised fp32 activation (act_out), the BatchNorm partial sums,
+    bit-reproducibility over repetitions, and the 'not eligible' answer for a shape the policy keeps off the persistent kernel."""
+    g = torch.Generator().manual_seed(M + Cin)
+    raw = torch.randn(M, Cin, generator=g).to(DEV)
+    scale = (torch.rand(Cin, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cin, generator=g) * 0.3).to(DEV)
+    resid = torch.randn(M, Cin, generator=g).to(DEV) if res else None
+    w = (torch.randn(CO, Cin, generator=g) / Cin ** 0.5).to(DEV)
+    act = torch.addcmul(shift, raw, scale)                      # raw * scale + shift (fused multiply-add, as the kernels contract it)
+    if res:
+        act = act + resid
+    if relu:
+        act = torch.relu(act)
+
+    def split(x2d):
+        R, K = x2d.shape
+        out = [torch.empty((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3)]
+        check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+        return out
+
+    planes = lambda ps: (C.c_void_p * 3)(*[t.data_ptr() for t in ps])                    # noqa: E731
+    wp = split(w)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    # ---- two-step route through the plane format
+    ap = split(act.contiguous())
+    y_ref = torch.full((M, CO), float("nan"), device=DEV)
+    part_ref = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+    mt = C.c_int(0)
+    check(lib.dic_debug_conv_bf3(planes(ap), 1, 1, M, Cin, planes(wp), CO, 1, 1, 0, ptr(y_ref), ptr(part_ref), C.byref(mt), ptr(tail),
+                                 stream_ptr()), "dic_debug_conv_bf3")
+    # ---- on-the-fly operand
+    outs = []
+    for rep in range(3):
+        y = torch.full((M, CO), float("nan"), device=DEV)
+        a_out = torch.full((M, Cin), float("nan"), device=DEV)
+        part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+        mt2 = C.c_int(0)
+        rc = lib.dic_debug_conv1x1_bn(ptr(raw), ptr(scale), ptr(shift), ptr(resid), relu, ptr(a_out), M, Cin, planes(wp), CO, ptr(y),
+                                      ptr(part), C.byref(mt2), ptr(tail), 1024, stream_ptr())
+        assert rc == 0, (rc, lib.dic_last_error())
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all() and torch.isfinite(a_out).all()
+        outs.append((y, a_out, part[: mt2.value * 2 * CO].view(mt2.value, 2, CO).double().sum(0).cpu()))
+        if rep:
+            assert torch.equal(outs[0][0], y) and torch.equal(outs[0][1], a_out), f"repetition {rep} differs"
+    y, a_out, stats = outs[0]
+    assert float((a_out - act).abs().max()) <= 1e-6 * float(act.abs().max()), "materialised activation"
+    ref64 = act.double().cpu() @ w.double().cpu().t()
+    sc = float(ref64.abs().max())
+    e_fused, e_two = float((y.double().cpu() - ref64).abs().max()) / sc, float((y_ref.double().cpu() - ref64).abs().max()) / sc
+    print(f"\n{M}x{CO}x{Cin}: max err / scale vs fp64: on-the-fly operand {e_fused:.2e}, plane route {e_two:.2e}; "
+          f"bit-identical outputs: {bool(torch.equal(y, y_ref))}")
+    assert e_fused <= 2.0 * e_two + 1e-6 and e_fused < 5e-6
+    yd = y.double().cpu()
+    assert torch.allclose(stats[0], yd.sum(0), rtol=1e-5, atol=1e-4 * sc) and torch.allclose(stats[1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * sc)
+    # a shape the launch policy does not put on the persistent kernel (64 output channels): nothing is launched, the caller is told
+    w64 = split(w[:64].contiguous())
+    y64 = torch.full((M, 64), float("nan"), device=DEV)
+    rc = lib.dic_debug_conv1x1_bn(ptr(raw), ptr(scale), ptr(shift), None, 1, None, M, Cin, planes(w64), 64, ptr(y64), None, None, ptr(tail),
+                                  1024, stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 1 and torch.isnan(y64).all()
