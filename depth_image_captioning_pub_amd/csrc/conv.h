@@ -34,6 +34,7 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse = nullptr,
                        int* bn_fused = nullptr);
+bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs);
 constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a larger tail region: every CU can take a remainder piece
 // bn_fuse: when the launch is tail-split, finalize the train-mode BatchNorm inside the fix-up launch (*bn_fused = 1)
 // data gradient of a stride-1 convolution through the same kernel: dy planes [B,OH,OW,CO], flipped weights

@@ -341,7 +341,11 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       // block output relu(bn3(R3) + identity); identity = the block input (planes Xp, or fp32 when conv1 formed it) or, in the first
       // block of a stage, the downsample branch
       const bool last = (s == 3 && b == blocks[s] - 1);
-      if ((g_fuse_bn_operand & 1) && b + 1 < blocks[s] && (b == 0 || in32)) {
+      // (decided here, by the next conv1's shape: a shape the persistent kernel does not take would pay for the fp32 copy on top of
+      //  the planes)
+      const bool next_fused = (g_fuse_bn_operand & 1) && b + 1 < blocks[s] && (b == 0 || in32) &&
+                              conv1x1_bf3_bn_eligible(c3.d.M(), c3.d.CO, c1.d.CO, kResnetTailSlabs);
+      if (next_fused) {
         // left to the next block's conv1.  The downsample output is normalised in place first (the kernel adds a plain residual)
         if (b == 0) DIC_TRY(bn_apply(Cf, nullptr, Cf, c3.d.M(), c3.d.CO, ws.bn_ds, 0, st));
         pend_res = b == 0 ? Cf : in32;

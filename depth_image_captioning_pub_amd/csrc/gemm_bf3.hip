@@ -1104,7 +1104,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
 }
 
 static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 1, float* splitk_ws = nullptr,
-                      const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr, int tail_ws_slabs = 256) {
+                      const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr, int tail_ws_slabs = 256, bool probe = false) {
   // tile choice (measured, scripts/bench_bf3.py): bigger per-wave tiles halve the LDS fragment traffic per MFMA and
   // amortise the per-K-tile barrier, but need >= ~2 workgroups per CU to keep 256 CUs busy
   int tmv = 1, tnv = 1;
@@ -1224,6 +1224,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   if (p.a_raw && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) return 1;      // on-the-fly operand: persistent 1x1 kernel or nothing
+  if (probe) return DIC_OK;                 // conv1x1_bf3_bn_eligible: the decision only
   gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
   if (persist && (halo || !ws256) && (halo || g_bf3_ws) && g_bf3_ablate == 0) {      // the product's 128x128 kernels
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
@@ -1319,6 +1320,19 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
 // persistent warp-specialised kernel instead of in a bn_apply_planes pass (20 B per element of HBM traffic and a launch less).
 // act_out (nullable) receives the fp32 input values once.  Returns DIC_OK, 1 when the launch policy would not run this shape on
 // that kernel (nothing launched: the caller takes the bn_apply_planes route), or a negative error.
+// would conv1x1_fwd_bf3_bn run this shape (the launch policy's answer, nothing launched)?
+bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs) {
+  if (C % 32 != 0 || C > kBnTabMax || (long long)M * C * 4 >= (1ll << 32)) return false;
+  static float dummy;                         // stands for "a tail workspace is there"; never dereferenced
+  Bf3Params p{};
+  p.M = M; p.N = CO; p.K = C;
+  p.A.kind = OPK_ROWK; p.A.ld = C; p.A.paired = 1;
+  p.B.kind = OPK_ROWK; p.B.ld = C; p.B.paired = 1;
+  p.a_raw = &dummy;
+  p.ep = ep_store(&dummy, CO, nullptr, ACT_NONE);
+  return launch_bf3(p, nullptr, &dummy, 1, nullptr, nullptr, nullptr, tail_ws_slabs, true) == DIC_OK;
+}
+
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused) {

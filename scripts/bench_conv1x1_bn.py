@@ -1,0 +1,79 @@
+"""Times conv1x1_fwd_bf3_bn (on-the-fly BatchNorm/residual/ReLU/split operand) against the plane route on ResNet shapes:
+python3 scripts/bench_conv1x1_bn.py [--batch 64].  Per shape: planes conv alone, bn_apply-equivalent + conv is not timed here
+(see scripts/agg_trace.py); fused with residual + fp32 copy / residual only / neither."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from depth_image_captioning_pub_amd import _lib  # noqa: E402
+from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+lib = _lib.load()
+DEV = "cuda:0"
+
+
+def split(x2d):
+    R, K = x2d.shape
+    out = [torch.empty((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3)]
+    check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+    return out
+
+
+def planes(ps):
+    return (C.c_void_p * 3)(*[t.data_ptr() for t in ps])
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.iters * 1e3
+
+
+B = a.batch
+for name, M, Cin, CO in (("layer2 conv1", B * 784, 512, 128), ("layer2 conv3", B * 784, 128, 512), ("layer3 conv1", B * 196, 1024, 256),
+                         ("layer3 conv3", B * 196, 256, 1024), ("layer4 conv1", B * 49, 2048, 512), ("layer4 conv3", B * 49, 512, 2048),
+                         ("layer1 conv3", B * 3136, 64, 256)):
+    raw = torch.randn(M, Cin, device=DEV)
+    res = torch.randn(M, Cin, device=DEV)
+    out = torch.empty(M, Cin, device=DEV)
+    scale = torch.rand(Cin, device=DEV) + 0.5
+    shift = torch.randn(Cin, device=DEV)
+    w = torch.randn(CO, Cin, device=DEV) / Cin ** 0.5
+    wp, ap_ = split(w), split(raw)
+    y = torch.empty(M, CO, device=DEV)
+    part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    mt = C.c_int(0)
+
+    def plane_route():
+        check(lib.dic_debug_conv_bf3(planes(ap_), 1, 1, M, Cin, planes(wp), CO, 1, 1, 0, ptr(y), ptr(part), C.byref(mt), ptr(tail), stream_ptr()), "conv")
+
+    def fused(r, o):
+        def f():
+            rc = lib.dic_debug_conv1x1_bn(ptr(raw), ptr(scale), ptr(shift), ptr(res) if r else None, 1, ptr(out) if o else None, M, Cin, planes(wp),
+                                          CO, ptr(y), ptr(part), C.byref(mt), ptr(tail), 1024, stream_ptr())
+            assert rc in (0, 1), rc
+            return rc
+        return f
+
+    t0 = timeit(plane_route)
+    if fused(False, False)() == 1:
+        print(f"{name:13s} M={M} {Cin}->{CO}: planes {t0:7.1f} us; not on the persistent kernel")
+        continue
+    t = [timeit(fused(r, o)) for r, o in ((True, True), (True, False), (False, False))]
+    print(f"{name:13s} M={M} {Cin}->{CO}: planes {t0:7.1f} us; on-the-fly res+copy {t[0]:7.1f}, res {t[1]:7.1f}, plain {t[2]:7.1f} us")

@@ -214,6 +214,38 @@ def test_resnet152_full_depth(lib, mode):
     _close("features", y, y_ref, 5e-3)
 
 
+def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(lib):
+    """Batch-64 ResNet-152 forward (the size at which the launch policy puts the 1x1 convolutions on the persistent kernel), train-mode
+    BatchNorm: with the BatchNorm-apply / residual / ReLU / split passes folded into the operand path of the consuming 1x1 convolutions
+    (switch 103, the default; 101 / 102 = block inputs only / conv3 inputs only) the feature map and every running statistic must agree
+    with the route that writes every convolution input as planes first (switch 100) bit for bit: the element-wise arithmetic (one
+    fused multiply-add, one add, max, the round-to-nearest-even three-way split) and the order of the products are the same, only the
+    kernel that performs them differs."""
+    w = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(64, seed=123).to(DEV)
+    results = {}
+    try:
+        for code in (100, 101, 102, 103, 103):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            wd = _dev(w)
+            y = native.ResNetRunner(wd, conv_mode="bf16x3").forward(imgs, train_bn=True, compact=True)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all()
+            stats = torch.cat([wd[k].flatten() for k in sorted(wd) if "running" in k])
+            if code in results:
+                assert torch.equal(results[code][0], y) and torch.equal(results[code][1], stats), "switch 103 does not reproduce itself"
+            results[code] = (y.clone(), stats.clone())
+    finally:
+        lib.dic_debug_force_staged_gemm(103)
+    y0, s0 = results[100]
+    scale = float(y0.abs().max())
+    for code in (101, 102, 103):
+        y, st = results[code]
+        dy, ds = float((y - y0).abs().max()) / scale, float((st - s0).abs().max()) / float(s0.abs().max())
+        print(f"switch {code} vs 100: features max |d| / max = {dy:.2e}, running statistics {ds:.2e}")
+        assert torch.equal(y, y0) and torch.equal(st, s0), (code, dy, ds)
+
+
 def test_layer1_kernels_reproducible_next_to_lds_heavy_kernels(lib):
     """The packed-FMA layer-1 kernels of the depth encoder (csrc/conv1_depth.hip), called alone through the library, repeated
     on identical inputs while a bf16x3 ResNet forward on its round-1 gather kernels (debug codes 70 75: three LDS-heavy
