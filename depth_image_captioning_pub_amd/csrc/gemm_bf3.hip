@@ -179,6 +179,52 @@ struct Bf3Loader {
   }
 };
 
+// Row-major (OPK_ROWK) paired planes through buffer loads: per output tile one 32-bit byte offset per lane and row group; per K
+// tile the instruction's scalar offset moves along K - no vector instructions at all in the K loop (the pointer form above
+// spends ~7 per DMA on 64-bit address arithmetic, row clamping and the M0 value: ~80 per K tile and wave, issued on the SIMD the
+// computing wave runs on).  Rows past the end of the operand get an offset beyond num_records: the load returns zeros (the
+// scalar offset is not part of the range check on gfx9).  Needs K % 32 == 0 and planes below 2 GiB (launch_bf3 checks).
+template <int BR>
+struct Bf3BufLoader {
+  static constexpr int NI = BR / 64;
+  __amdgpu_buffer_rsrc_t rs[3];
+  unsigned voff[NI];
+  int kstep;                  // bytes per K tile
+  __device__ __forceinline__ void init(const Bf3Operand& op, int r0, int R, int) {
+    const int kb = (int)(op.ld / 32);
+    const long long bytes = op.paired ? (long long)((R + 1) / 2) * kb * 128 : (long long)R * op.ld * 2;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) rs[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)op.p[pl], 0, (int)bytes, 0x00020000);
+    kstep = op.paired ? 128 : 64;
+    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int row = (n * 4 + w) * 16 + (lane >> 2);
+      const int gr = r0 + row;
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      voff[n] = gr < R ? (unsigned)(plane_offset(gr, chunk * 8, kb, op.paired) * 2) : 0x80000000u;
+    }
+  }
+  __device__ __forceinline__ void issue_plain(int k0, unsigned short* img) const {
+    const int w = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+    const int soff = (k0 >> 5) * kstep;
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        unsigned short* dst = img + pl * BR * BK3 + ((n * 4 + w) * 16) * BK3;       // wave-uniform 1-KiB block
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[pl], (__attribute__((address_space(3))) void*)dst, 16, voff[n], soff, 0, 0);
+      }
+  }
+  template <int AUX = 0>      // (same call form as Bf3Loader; the builtin itself sits in a non-template member: the host pass of the compiler rejects it inside one)
+  __device__ __forceinline__ void issue(int k0, unsigned short* img) const {
+    static_assert(AUX == 0, "Bf3BufLoader: default cache policy only");
+    issue_plain(k0, img);
+  }
+};
+template <int KIND, int BR> struct Bf3LoaderFor { typedef Bf3Loader<KIND, BR> type; };
+template <int BR> struct Bf3LoaderFor<OPK_ROWK, BR> { typedef Bf3BufLoader<BR> type; };
+
 __device__ __forceinline__ void bf3_lds_read(u32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
@@ -414,7 +460,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     const int pt = tid - 256, prow0 = (pt >> 6) * 32 + ((pt & 63) >> 3), kq = pt & 7;
     __builtin_amdgcn_s_setprio(3);       // the transform's vector instructions go ahead of the computing wave of the same SIMD
     const bool has_res = p.a_res != nullptr;
-    Bf3Loader<OPK_ROWK, BN> lbld;
+    typename Bf3LoaderFor<OPK_ROWK, BN>::type lbld;
     // ---- slot iterators: (work item, K tile) of the next B slot to issue / next A slot to load / next A slot to transform
     struct It { int j, kt, k0, nk; };
     auto it_init = [&](It& it) { it.j = 0; it.kt = 0; it.k0 = ntl > 0 ? 0 : pk0; it.nk = ntl > 0 ? nkt : npk; };
@@ -602,8 +648,8 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   } else
   if (wave >= 4) {
     // ---------------- producer waves: slot g of the stream goes to ring stage g % NST
-    Bf3Loader<AK, BM> la;
-    Bf3Loader<OPK_ROWK, BN> lbld;
+    typename Bf3LoaderFor<AK, BM>::type la;
+    typename Bf3LoaderFor<OPK_ROWK, BN>::type lbld;
     int pj = 0, pkt = 0, k0cur = ntl > 0 ? 0 : pk0, nkcur = ntl > 0 ? nkt : npk;
     {
       const int t = ntl > 0 ? xcd_remap(blockIdx.x, F) : piece_tile;
@@ -1130,7 +1176,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // it wins where a tile is only a few K tiles long and the grid is many rounds deep - the 1x1 expansions 64 -> 256
   // (-12 % per launch at batch 64, -20 % at batch 256), and at batch-256 scale also 128 -> 512 and 256 -> 1024.
   const bool plain_ep = !p.ep.bias && !p.ep.accumulate && p.ep.act == ACT_NONE;      // what the halo kernel (and the parked forms) store
-  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && p.N % 128 == 0 && (plain_ep || g_bf3_ws);
+  // (row-major operands of the persistent kernels go through 32-bit buffer offsets: K in whole 32-element tiles, planes below 2 GiB)
+  const bool buf_ok = p.K % BK3 == 0 && p.B.ld % 32 == 0 && (long long)(p.N + 1) * p.B.ld * 2 < (1ll << 31) &&
+                      (p.A.kind != OPK_ROWK || (p.A.ld % 32 == 0 && (long long)(p.M + 1) * p.A.ld * 2 < (1ll << 31)));
+  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && p.N % 128 == 0 && (plain_ep || g_bf3_ws) && buf_ok;
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
   double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
