@@ -92,6 +92,18 @@ __device__ __forceinline__ void split3_bf16(float v, unsigned short& h, unsigned
   l = bf16_rne_bits(r1 - bf16_bits_to_f32(m));
 }
 
+constexpr float kF16ActScale = 4.0f;       // f16x2 ACTIVATION planes hold 4 * x: |x| up to 16376 (larger values become inf: a loud failure); weights carry a
+                                           // per-layer scale that puts their largest magnitude in [2^14, 2^15)
+// fp32 -> two fp16 planes of s*v (s a power of two chosen by the caller): h1 = rn(s*v), h2 = rn(s*v - h1); |s*v - h1 - h2| <= 2^-22 |s*v|
+// (h2 may be subnormal: the matrix cores honour it).  Values beyond the fp16 range become inf - the caller's scale must prevent that.
+__device__ __forceinline__ void split2_f16(float v, float s, unsigned short& h1, unsigned short& h2) {
+  const float x = v * s;
+  const _Float16 a = (_Float16)x;
+  const _Float16 b = (_Float16)(x - (float)a);
+  h1 = __builtin_bit_cast(unsigned short, a);
+  h2 = __builtin_bit_cast(unsigned short, b);
+}
+
 // Bijective XCD-aware block remap (guide T1): blocks b and b+8 share an XCD (speed only).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;

@@ -27,13 +27,15 @@ int conv_mtiles(const ConvDesc& d, int force_tile = 0);
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st,
                  const float* bias = nullptr, const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr,
-                 int act = 0 /* ACT_NONE */, int tail_ws_slabs = 256 /* [64][64]-float slabs in tail_ws (kGemmTailWsBytes = 256) */);
+                 int act = 0 /* ACT_NONE */, int tail_ws_slabs = 256 /* [64][64]-float slabs in tail_ws (kGemmTailWsBytes = 256) */,
+                 int fmt = 0 /* operand format: 0 = bf16x3, 1 = f16x2 (two fp16 planes of scaled values, gemm_bf3.hip) */,
+                 float out_scale = 1.0f /* f16x2: 1 / (scale of the x planes * scale of the w planes) */);
 // 1x1 convolution with the BatchNorm-apply (+ residual) + ReLU + split of its input fused into the operand path (gemm_bf3.hip);
 // returns 1 (nothing launched) when the shape would not run on the persistent warp-specialised kernel
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse = nullptr,
-                       int* bn_fused = nullptr);
+                       int* bn_fused = nullptr, int fmt = 0, float out_scale = 1.0f);
 bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs);
 constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a larger tail region: every CU can take a remainder piece
 // bn_fuse: when the launch is tail-split, finalize the train-mode BatchNorm inside the fix-up launch (*bn_fused = 1)
@@ -56,6 +58,7 @@ int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& 
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
                         unsigned short* lo, hipStream_t st);
+int split_f16x2_paired(const float* x, long long rows, int K, float scale, unsigned short* h1, unsigned short* h2, hipStream_t st);
 
 // Depth-encoder layer 1 (1 -> 128 channels, 7x7, stride 3, no padding) on packed fp32 vector FMAs (conv1_depth.hip).
 //   fwd: y [B,OH,OW,128] = conv(x [B,H,W]) + bias; bn_partial (nullable) receives one [2][128] row of sums per workgroup,

@@ -16,7 +16,16 @@
 namespace dic {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Operand formats of this file's kernels (template parameter FMT):
+//   0  "bf16x3": three bf16 planes, six products (above) - exact decomposition, fp32-level result
+//   1  "f16x2":  two fp16 planes h1 + h2 of s*x (s a power of two that puts the operand's values high in the fp16 range;
+//      h1 = rn(s*x), h2 = rn(s*x - h1): |s*x - h1 - h2| <= 2^-22 |s*x|, subnormal h2 are honoured by the matrix cores - checked,
+//      scripts/micro/mfma_f16_subnormal.hip) and the three products h1*h1' + h1*h2' + h2*h1' (dropped: h2*h2' <= 2^-22 |ab|):
+//      a few fp32 round-offs per product instead of one, at half the matrix-core work and two thirds of the operand bytes.
+//      The epilogue multiplies the accumulators by ep.alpha = 1 / (s_a * s_b) (exact).
+template <int FMT> struct Bf3Fmt { static constexpr int NPL = FMT == 1 ? 2 : 3; };
 constexpr int BK3 = 32;          // K tile in elements (64 B per plane row)
 #ifndef DIC_WS_A_AUX
 #define DIC_WS_A_AUX 0    // cache policy of the streamed A operand in the warp-specialised kernel (2 = nt measured within +-3 %: left at default)
@@ -60,6 +69,27 @@ __global__ void __launch_bounds__(256) split_bf16x3_paired_kernel(const float* _
   }
 }
 
+// f16x2 format (top of the file), same row-pair interleaved layout: two planes of scale * x
+__global__ void __launch_bounds__(256) split_f16x2_paired_kernel(const float* __restrict__ x, long long rows, int K, float scale,
+                                                                  unsigned short* __restrict__ h1, unsigned short* __restrict__ h2) {
+  const long long n4 = ((rows + 1) >> 1) * (K / 2);
+  const int kb = K / 32;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const long long line = i >> 4;
+    const int j = (int)(i & 15);
+    const long long r = (line / kb) * 2 + (j >> 3);
+    const int k = (int)(line % kb) * 32 + (j & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *reinterpret_cast<const float4*>(x + r * K + k);
+    unsigned short a[4], b[4];
+    split2_f16(v.x, scale, a[0], b[0]); split2_f16(v.y, scale, a[1], b[1]);
+    split2_f16(v.z, scale, a[2], b[2]); split2_f16(v.w, scale, a[3], b[3]);
+    reinterpret_cast<uint2*>(h1)[i] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
+    reinterpret_cast<uint2*>(h2)[i] = make_uint2((unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16));
+  }
+}
+
 struct Bf3Operand {
   const unsigned short* p[3];   // hi, mid, lo planes, element (i,k) at p[.][i*ld + k]  (or NHWC image for im2col)
   long long ld;
@@ -84,13 +114,14 @@ struct Bf3Params {
   float* a_out;
   long long a_ld;
   int a_relu;
+  int fmt;                      // operand format of A and B: 0 = bf16x3, 1 = f16x2 (ep.alpha then carries 1 / (scale_a * scale_b))
 };
 constexpr int OPK_ROWK_BN = 6;     // (A-operand kind of the kernel template; never stored in Bf3Operand::kind)
 constexpr int kBnTabMax = 2048;    // channels of the on-the-fly operand (its scale / shift table lives in LDS)
 
 // One operand's DMA bookkeeping: a wave-instruction fills 16 rows x 64 B of one plane image; wave w takes the row
 // groups w, w+4, ... of each of the three planes.  Address arithmetic is done once per output tile.
-template <int KIND, int BR>
+template <int KIND, int BR, int NPL = 3>
 struct Bf3Loader {
   static constexpr int NI = BR / 64;
   const unsigned short* p[3];
@@ -169,7 +200,7 @@ struct Bf3Loader {
         }
       }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
         const unsigned short* src = ok ? p[pl] + off : g_zero_line16;
         unsigned short* dst = img + pl * BR * BK3 + ((n * 4 + w) * 16) * BK3;       // wave-uniform 1-KiB block
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -184,7 +215,7 @@ struct Bf3Loader {
 // spends ~7 per DMA on 64-bit address arithmetic, row clamping and the M0 value: ~80 per K tile and wave, issued on the SIMD the
 // computing wave runs on).  Rows past the end of the operand get an offset beyond num_records: the load returns zeros (the
 // scalar offset is not part of the range check on gfx9).  Needs K % 32 == 0 and planes below 2 GiB (launch_bf3 checks).
-template <int BR>
+template <int BR, int NPL = 3>      // NPL: planes of the operand format
 struct Bf3BufLoader {
   static constexpr int NI = BR / 64;
   __amdgpu_buffer_rsrc_t rs[3];
@@ -194,7 +225,7 @@ struct Bf3BufLoader {
     const int kb = (int)(op.ld / 32);
     const long long bytes = op.paired ? (long long)((R + 1) / 2) * kb * 128 : (long long)R * op.ld * 2;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) rs[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)op.p[pl], 0, (int)bytes, 0x00020000);
+    for (int pl = 0; pl < NPL; ++pl) rs[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)op.p[pl], 0, (int)bytes, 0x00020000);
     kstep = op.paired ? 128 : 64;
     const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
 #pragma unroll
@@ -211,7 +242,7 @@ struct Bf3BufLoader {
 #pragma unroll
     for (int n = 0; n < NI; ++n)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
         unsigned short* dst = img + pl * BR * BK3 + ((n * 4 + w) * 16) * BK3;       // wave-uniform 1-KiB block
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[pl], (__attribute__((address_space(3))) void*)dst, 16, voff[n], soff, 0, 0);
       }
@@ -222,22 +253,29 @@ struct Bf3BufLoader {
     issue_plain(k0, img);
   }
 };
-template <int KIND, int BR> struct Bf3LoaderFor { typedef Bf3Loader<KIND, BR> type; };
-template <int BR> struct Bf3LoaderFor<OPK_ROWK, BR> { typedef Bf3BufLoader<BR> type; };
+template <int KIND, int BR, int NPL = 3> struct Bf3LoaderFor { typedef Bf3Loader<KIND, BR, NPL> type; };
+template <int BR, int NPL> struct Bf3LoaderFor<OPK_ROWK, BR, NPL> { typedef Bf3BufLoader<BR, NPL> type; };
 
 __device__ __forceinline__ void bf3_lds_read(u32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+template <int FMT>
+__device__ __forceinline__ f32x16_ bf3_mfma(const u32x4& a, const u32x4& b, const f32x16_& c) {
+  if constexpr (FMT == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // Workgroup tile (64*TM) x (64*TN), 4 waves (2x2), each wave TM x TN MFMA tiles of 32x32.
-template <int AK, int TM, int TN, int NSTAGE, int ABL = 0>
+template <int AK, int TM, int TN, int NSTAGE, int ABL = 0, int FMT = 0>
 __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, WM = 32 * TM, WN = 32 * TN;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3;      // elements per plane image
   constexpr int AOPER = 3 * APLANE, BOPER = 3 * BPLANE;
   constexpr int STAGE = AOPER + BOPER;
-  constexpr int NDMA = 3 * (TM + TN);                      // DMA instructions per wave and K tile
-  constexpr int NRD = 3 * (TM + TN);                       // fragment reads per wave and k-step
+  constexpr int NPL = Bf3Fmt<FMT>::NPL;                    // planes in use (the stage keeps three plane slots per operand)
+  constexpr int NDMA = NPL * (TM + TN);                    // DMA instructions per wave and K tile
+  constexpr int NRD = NPL * (TM + TN);                     // fragment reads per wave and k-step
   __shared__ __align__(1024) unsigned short smem[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -257,8 +295,8 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
   }
   const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
 
-  Bf3Loader<AK, BM> la;
-  Bf3Loader<OPK_ROWK, BN> lbld;
+  Bf3Loader<AK, BM, NPL> la;
+  Bf3Loader<OPK_ROWK, BN, NPL> lbld;
   la.init(p.A, tm * BM, p.M, p.K);
   lbld.init(p.B, tn * BN, p.N, p.K);
   const int nkt = max(kt1 - kt0, 0);
@@ -291,7 +329,7 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
     const bool more = it + NSTAGE - 1 < nkt;
     unsigned short* nx = smem + ((it + NSTAGE - 1) % NSTAGE) * STAGE;
     const unsigned sb = sbase0 + (unsigned)((it % NSTAGE) * STAGE) * 2u;
-    if constexpr (TM == 1 && TN == 1) {
+    if constexpr (TM == 1 && TN == 1 && FMT == 0) {
       // 64x64 tile: one fused asm block issues all 12 fragment reads (measured ~8 % faster than per-read statements)
       const unsigned a0 = sb + offA, b0 = sb + (unsigned)(AOPER * 2) + offB;
       constexpr unsigned PA = APLANE * 2, PBb = BPLANE * 2;        // plane strides in bytes
@@ -342,12 +380,12 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
           bf3_lds_read(fa[ks][i][pl], sb + (unsigned)(pl * APLANE * 2) + offA + (unsigned)(i * 32 * 64) + pos[ks]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
           bf3_lds_read(fb[ks][j][pl], sb + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)(j * 32 * 64) + pos[ks]);
     }
 #pragma unroll
@@ -362,21 +400,19 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(fa[ks][i][pl]));
+        for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(fa[ks][i][pl]));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(fb[ks][j][pl]));
+        for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(fb[ks][j][pl]));
       __builtin_amdgcn_sched_barrier(0);
-#define DIC_BF3_MFMA(I_, J_, PA_, PB_)                                                                           \
-  acc[I_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks][I_][PA_]),             \
-                                                        __builtin_bit_cast(bf16x8, fb[ks][J_][PB_]), acc[I_][J_], 0, 0, 0);
+#define DIC_BF3_MFMA(I_, J_, PA_, PB_) acc[I_][J_] = bf3_mfma<FMT>(fa[ks][I_][PA_], fb[ks][J_][PB_], acc[I_][J_]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           // small terms first: al*bh, ah*bl, am*bm, am*bh, ah*bm, ah*bh   (plane 0 = hi, 1 = mid, 2 = lo)
-          DIC_BF3_MFMA(i, j, 2, 0) DIC_BF3_MFMA(i, j, 0, 2) DIC_BF3_MFMA(i, j, 1, 1)
+          if constexpr (FMT == 0) { DIC_BF3_MFMA(i, j, 2, 0) DIC_BF3_MFMA(i, j, 0, 2) DIC_BF3_MFMA(i, j, 1, 1) }
           DIC_BF3_MFMA(i, j, 1, 0) DIC_BF3_MFMA(i, j, 0, 1) DIC_BF3_MFMA(i, j, 0, 0)
           if (ks == 0 && i == 0 && j == 0 && more) {      // next tile's DMA goes out in the MFMA shadow
             la.issue((kt0 + it + NSTAGE - 1) * BK3, nx);
@@ -413,12 +449,13 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 // (scripts/bench_bf3_pipe_ablate.py) - a global_load_lds that cannot issue (address arithmetic, M0 set-up, a full
 // vector-memory queue) blocks the MFMAs queued behind it in the same wave.  A producer wave that blocks costs nothing.
 // Two waves per SIMD, so the kernel has to fit 256 registers; the stores of a seam and the DMA no longer share a vmcnt.
-template <int AK, int ABL = 0, int NST = 3>      // ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
+template <int AK, int ABL = 0, int NST = 3, int FMT = 0>      // FMT: operand format (top of the file); ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
 __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128;
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];
   constexpr bool kBn = AK == OPK_ROWK_BN;
+  constexpr int NPL = Bf3Fmt<FMT>::NPL;       // planes in use (the stage keeps three plane slots per operand)
   __shared__ float bn_tab[kBn ? 2 * kBnTabMax : 1];      // scale | shift of the on-the-fly operand (144 + 16 KB = all of the LDS)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -460,7 +497,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     const int pt = tid - 256, prow0 = (pt >> 6) * 32 + ((pt & 63) >> 3), kq = pt & 7;
     __builtin_amdgcn_s_setprio(3);       // the transform's vector instructions go ahead of the computing wave of the same SIMD
     const bool has_res = p.a_res != nullptr;
-    typename Bf3LoaderFor<OPK_ROWK, BN>::type lbld;
+    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
     // ---- slot iterators: (work item, K tile) of the next B slot to issue / next A slot to load / next A slot to transform
     struct It { int j, kt, k0, nk; };
     auto it_init = [&](It& it) { it.j = 0; it.kt = 0; it.k0 = ntl > 0 ? 0 : pk0; it.nk = ntl > 0 ? nkt : npk; };
@@ -571,6 +608,20 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
         if ((S.flg & 16u) && ((S.flg >> i) & 1u))
           *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.a_out) + (size_t)(S.off0 + (unsigned)(8 * i) * ldb)) =
               make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        const unsigned dst = sbase + doff[i];
+        if constexpr (FMT == 1) {         // two fp16 planes of kF16ActScale * v
+          typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+          u32x2_ q1, q2;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x2_ xx = f32x2_{v[i][2 * u], v[i][2 * u + 1]} * kF16ActScale;
+            const f16x2_ h1 = __builtin_convertvector(xx, f16x2_);
+            const f32x2_ r1 = xx - __builtin_convertvector(h1, f32x2_);
+            q1[u] = __builtin_bit_cast(unsigned, h1); q2[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_));
+          }
+          asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(q1) : "memory");
+          asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(q2), "i"(APLANE * 2) : "memory");
+        } else {
         u32x2_ qh, qm, ql;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -581,10 +632,10 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
           const f32x2_ r2 = {r1.x - __uint_as_float(mb << 16), r1.y - __uint_as_float(mb & 0xffff0000u)};
           qh[u] = hb; qm[u] = mb; ql[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bfx2));
         }
-        const unsigned dst = sbase + doff[i];
         asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(qh) : "memory");
         asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(qm), "i"(APLANE * 2) : "memory");
         asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(ql), "i"(2 * APLANE * 2) : "memory");
+        }
       }
     };
     // ---- prologue: B slots 0..2 and A slots 0..DA-1 in flight; slot 0 transformed; then A slot DA
@@ -605,8 +656,8 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     auto wait_early = [&]() {            // at most (DA - 1) * nl outstanding
       if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 8) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 4) : "memory");
     };
-    auto wait_steady = [&]() {           // at most (DA - 1) * (6 + nl) outstanding
-      if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 14) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 10) : "memory");
+    auto wait_steady = [&]() {           // at most (DA - 1) * (2 * NPL + nl) outstanding
+      if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (2 * NPL + 8)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (2 * NPL + 4)) : "memory");
     };
     if (steady_ok) wait_early(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DIC_PIN_SLOT(sets[0]);
@@ -648,8 +699,8 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   } else
   if (wave >= 4) {
     // ---------------- producer waves: slot g of the stream goes to ring stage g % NST
-    typename Bf3LoaderFor<AK, BM>::type la;
-    typename Bf3LoaderFor<OPK_ROWK, BN>::type lbld;
+    typename Bf3LoaderFor<AK, BM, NPL>::type la;
+    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
     int pj = 0, pkt = 0, k0cur = ntl > 0 ? 0 : pk0, nkcur = ntl > 0 ? nkt : npk;
     {
       const int t = ntl > 0 ? xcd_remap(blockIdx.x, F) : piece_tile;
@@ -673,13 +724,13 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 #pragma unroll
     for (int s0 = 0; s0 < NST; ++s0)
       if (s0 < total) prefetch(smem + s0 * STAGE);
-    if (total >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (NST - 1)) : "memory");
+    if (total >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPL * (NST - 1)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
     int st = 0;
     for (int g = 0; g < total; ++g) {
       // before the consumers read slot g+1 (after this barrier) it must have landed; slot g+2 may stay in flight
-      if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPL) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
       if (ABL != 1 && g + NST < total) prefetch(smem + st * STAGE);
@@ -703,18 +754,17 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
   u32x4 fa[2][2][3], fb[2][2][3];
 #define DIC_PIPE_READ_A(KS_, SB_, I_)                                                                                \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+  _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                                 \
       bf3_lds_read(fa[KS_][I_][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)((I_) * 32 * 64) + pos[KS_]);
 #define DIC_PIPE_READ_B(KS_, SB_, J_)                                                                                \
-  _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                                   \
+  _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                                 \
       bf3_lds_read(fb[KS_][J_][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)((J_) * 32 * 64) + pos[KS_]);
 #define DIC_PIPE_PIN(KS_)                                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                 \
     asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
 #define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
-                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
+      acc[i][j] = bf3_mfma<FMT>(fa[KS_][i][PA_], fb[KS_][j][PB_], acc[i][j]);
   __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
   DIC_PIPE_READ_A(0, sbase0, 0) DIC_PIPE_READ_A(0, sbase0, 1) DIC_PIPE_READ_B(0, sbase0, 0) DIC_PIPE_READ_B(0, sbase0, 1)
   int g = 0, st = 0;
@@ -724,18 +774,20 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       const int stn = st == NST - 1 ? 0 : st + 1;
       const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
       DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
-      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+      if constexpr (NPL == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
       DIC_PIPE_PIN(0)
       __builtin_amdgcn_sched_barrier(0);
-      DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
+      if constexpr (NPL == 3) { DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) }
+      DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this stage is in registers
       DIC_PIPE_PIN(1)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      DIC_PIPE_MFMA(1, 2, 0)
+      if constexpr (NPL == 3) { DIC_PIPE_MFMA(1, 2, 0) } else { DIC_PIPE_MFMA(1, 1, 0) }
       if (g + 1 < total) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
-      DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0) DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
+      if constexpr (NPL == 3) { DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0) }
+      DIC_PIPE_MFMA(1, 0, 1) DIC_PIPE_MFMA(1, 0, 0)
       __builtin_amdgcn_sched_barrier(0);
       st = stn;
     }
@@ -752,6 +804,14 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
                             : p.ep.C;
     const long long ldc = piece ? 64 : p.ep.ldc;
     float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+    if constexpr (FMT == 1) {             // undo the operands' power-of-two scales (a piece stays raw: the fix-up scales the sum)
+      if (!piece) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= p.ep.alpha;
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -825,12 +885,14 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 //     per K tile, weights three tiles ahead, the next chunk's halo issued at tap 0 of the current chunk (8 K tiles early);
 //   * summation order per output: chunk-major, tap-minor (the other kernels: tap-major) - same products, fp32-level
 //     differences in the last bit, not bit-identical to them.
-template <int ABL>      // ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
+template <int ABL, int FMT = 0>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
 __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128, NSTB = 3, HROW = 16, RMAX = 13;
   constexpr int HPLANE = RMAX * HROW * BK3, HBUF = 3 * HPLANE;        // elements: 13 KB per plane, 39 KB per buffer
   constexpr int BPLANE = BN * BK3, BSTAGE = 3 * BPLANE;               // 24 KB per weight tile
-  constexpr int NHALO = 10;                                            // halo DMA instructions per producer wave and chunk
+  constexpr int NPL = Bf3Fmt<FMT>::NPL;                               // planes in use (buffers keep three plane slots)
+  constexpr int NHALO = (RMAX * NPL + 3) / 4;                          // halo DMA instructions per producer wave and chunk (10 | 7)
+  constexpr int NB = 2 * NPL;                                          // weight DMA instructions per producer wave and K tile
   __shared__ __align__(1024) unsigned short smem[2 * HBUF + NSTB * BSTAGE + 512];
   unsigned short* const bring = smem + 2 * HBUF;
   unsigned short* const dummy = smem + 2 * HBUF + NSTB * BSTAGE;
@@ -878,8 +940,8 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       hok = 0u;
 #pragma unroll
       for (int t = 0; t < NHALO; ++t) {
-        const int idx = w + 4 * t;                          // (row, plane) = (idx / 3, idx % 3); idx 39 = the dummy
-        const int r = (idx * 43) >> 7;
+        const int idx = w + 4 * t;                          // (row, plane) = (idx / NPL, idx % NPL); rows >= 13 = the dummies
+        const int r = NPL == 3 ? (idx * 43) >> 7 : idx >> 1;
         for (int a = r_prev; a < r; ++a) { if (++rr == H + 1) { rr = 0; ++b; } }      // at most two steps
         r_prev = r;
         const int q = r * HROW + px, c16 = (lane & 3) ^ ((q >> 2) & 3);
@@ -895,15 +957,15 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       unsigned short* buf = smem + (n & 1) * HBUF;
 #pragma unroll
       for (int t = 0; t < NHALO; ++t) {
-        const int idx = w + 4 * t, r = (idx * 43) >> 7, pl = idx - 3 * r;
-        const unsigned short* src = ((hok >> t) & 1u) ? p.A.p[pl < 3 ? pl : 0] + (hoff[t] + cc * 64) : g_zero_line16;
+        const int idx = w + 4 * t, r = NPL == 3 ? (idx * 43) >> 7 : idx >> 1, pl = idx - NPL * r;
+        const unsigned short* src = ((hok >> t) & 1u) ? p.A.p[pl] + (hoff[t] + cc * 64) : g_zero_line16;
         unsigned short* dst = r < RMAX ? buf + pl * HPLANE + r * (HROW * BK3) : dummy;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     };
     // weight slot s = (tile, chunk, tap) in that order, K offset tap*C + 32*chunk
-    Bf3Loader<OPK_ROWK, BN> lbld;
+    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
     int pj = 0, pcc = ntl > 0 ? 0 : pc0, pend = ntl > 0 ? NC : pc0 + npc, ptap = 0, pst = 0;
     { int tm, tn; tile_of(0, tm, tn); lbld.init(p.B, tn * BN, p.N, p.K); }
     auto issue_b = [&]() {
@@ -922,7 +984,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
 #pragma unroll
     for (int s0 = 0; s0 < NSTB; ++s0)
       if (s0 < total) issue_b();
-    if (total >= NSTB) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // halo chunk 0 and weight tile 0 (6 each younger tile)
+    if (total >= NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");     // halo chunk 0 and weight tile 0 (NB each younger tile)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int g = 0, n = 0;
@@ -934,8 +996,8 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
           // weight tile g+1 (and, before tap 0 of a chunk, that chunk's halo - older still) must have landed; younger, in issue
           // order: the previous slot's halo chunk (10, if it issued one) and weight tile g+2 (6)
           if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else if (halo_prev) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (halo_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NHALO + NB) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
           __builtin_amdgcn_s_barrier();
           halo_prev = false;
           if (tap == 0 && n + 1 < nchunks) { if (!(ABL & 2)) issue_halo(n + 1); halo_prev = !(ABL & 2); }
@@ -970,18 +1032,17 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                    \
     const unsigned q = (unsigned)((QB_)[i] + (TAPOFF_));                                                             \
     const unsigned a = sbase0 + (unsigned)((HB_) * HBUF * 2) + q * 64u + ((((unsigned)(2 * (KS_) + h)) ^ ((q >> 2) & 3u)) << 4); \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) bf3_lds_read(fa[KS_][i][pl], a + (unsigned)(pl * HPLANE * 2));  \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) bf3_lds_read(fa[KS_][i][pl], a + (unsigned)(pl * HPLANE * 2)); \
   }
 #define DIC_HALO_READ_B(KS_, ST_)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
       bf3_lds_read(fb[KS_][j][pl], sbase0 + (unsigned)((2 * HBUF + (ST_) * BSTAGE + pl * BPLANE) * 2) + offB + (unsigned)(j * 32 * 64) + posB[KS_]);
 #define DIC_PIPE_PIN(KS_)                                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                 \
     asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[KS_][i][pl])); }
 #define DIC_PIPE_MFMA(KS_, PA_, PB_)                                                                                 \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[KS_][i][PA_]),               \
-                                                          __builtin_bit_cast(bf16x8, fb[KS_][j][PB_]), acc[i][j], 0, 0, 0);
+      acc[i][j] = bf3_mfma<FMT>(fa[KS_][i][PA_], fb[KS_][j][PB_], acc[i][j]);
 
   int qb[2], qbn[2];
   { int tm, tn; tile_of(0, tm, tn); qb[0] = pixel_base(tm, 0); qb[1] = pixel_base(tm, 1); }
@@ -999,16 +1060,17 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
         const int stn = st == NSTB - 1 ? 0 : st + 1;
         const int kh = tap >= 6 ? 2 : tap >= 3 ? 1 : 0, kw = tap - 3 * kh, tapoff = kh * HROW + kw;
         DIC_HALO_READ_A(1, hb, qb, tapoff) DIC_HALO_READ_B(1, st)
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 * NPL) : "memory");
         DIC_PIPE_PIN(0)
         __builtin_amdgcn_sched_barrier(0);
-        DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
+        if constexpr (NPL == 3) { DIC_PIPE_MFMA(0, 2, 0) DIC_PIPE_MFMA(0, 0, 2) DIC_PIPE_MFMA(0, 1, 1) }
+        DIC_PIPE_MFMA(0, 1, 0) DIC_PIPE_MFMA(0, 0, 1) DIC_PIPE_MFMA(0, 0, 0)
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         DIC_PIPE_PIN(1)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        DIC_PIPE_MFMA(1, 2, 0)
+        if constexpr (NPL == 3) { DIC_PIPE_MFMA(1, 2, 0) } else { DIC_PIPE_MFMA(1, 1, 0) }
         if (g + 1 < total) {                       // k-step 0 of the next slot: next tap / next chunk (other buffer) / next tile
           if (tap < 8) {
             const int t1 = tap + 1, kh1 = t1 >= 6 ? 2 : t1 >= 3 ? 1 : 0, off1 = kh1 * HROW + (t1 - 3 * kh1);
@@ -1020,7 +1082,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
           }
           DIC_HALO_READ_B(0, stn)
         }
-        DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0)
+        if constexpr (NPL == 3) { DIC_PIPE_MFMA(1, 0, 2) DIC_PIPE_MFMA(1, 1, 1) DIC_PIPE_MFMA(1, 1, 0) }
         if (tap == 1 && cc == ncj - 1 && j + 1 < nwork) {     // next tile's pixel bases, well before its first fragment reads
           int tm, tn; tile_of(j + 1, tm, tn);
           qbn[0] = pixel_base(tm, 0); qbn[1] = pixel_base(tm, 1);
@@ -1041,6 +1103,14 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
                             : p.ep.C;
     const long long ldc = piece ? 64 : p.ep.ldc;
     float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+    if constexpr (FMT == 1) {             // undo the operands' power-of-two scales (a piece stays raw: the fix-up scales the sum)
+      if (!piece) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= p.ep.alpha;
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -1114,6 +1184,7 @@ static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
     if (g_bf3_stages == 3) { hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 3>), dim3(blocks), dim3(256), 0, st, p); return; }
   }
 #endif
+  if (p.fmt == 1) { hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 2, 0, 1>), dim3(blocks), dim3(256), 0, st, p); return; }
   hipLaunchKernelGGL((gemm_bf3_kernel<AK, TM, TN, 2>), dim3(blocks), dim3(256), 0, st, p);
 }
 
@@ -1222,7 +1293,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   p.mtiles = ceil_div(p.M, 64 * tmv); p.ntiles = ceil_div(p.N, 64 * tnv);
   g_last_mtiles = p.mtiles;
   p.splitk = 1; p.ws = nullptr;
-  p.ep.alpha = 1.0f;
+  if (p.fmt != 1) p.ep.alpha = 1.0f;
   const int T = p.mtiles * p.ntiles, nk = ceil_div(p.K, BK3);
   int total = T;
   p.tail_first_block = T; p.tail_first_tile = 0; p.tail_split = 1; p.tail_ws = nullptr;
@@ -1279,6 +1350,12 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
     const int grid = persist_grid;
+    if (p.fmt == 1) {
+      if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
+    } else
     if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN>), dim3(grid), dim3(512), 0, st, p);
     else
     if (halo) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<0>, dim3(grid), dim3(512), 0, st, p);
@@ -1326,14 +1403,14 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   gemm_profile_mark_end(st);
   if (rem128 > 0) {        // finish the remainder tiles of a persistent launch (quadrant-wise: the fix-up works on 64x64 tiles)
     GemmParams g{};
-    g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.ep.alpha = 1.0f; g.mtiles = ceil_div(p.M, 64); g.ntiles = ceil_div(p.N, 64);
+    g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.mtiles = ceil_div(p.M, 64); g.ntiles = ceil_div(p.N, 64);      // (ep.alpha: 1, or the f16x2 unscale of the raw sums)
     g.tail_split = p.tail_split; g.tail_ws = p.tail_ws;
     g.tail128_first = p.tail_first_tile; g.tail128_ntiles = p.ntiles;
     DIC_TRY(gemm_launch_tail_fixup(g, rem128 * 4, st));
   }
   if (tail_tiles > 0) {
     GemmParams g{};
-    g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.ep.alpha = 1.0f; g.mtiles = p.mtiles; g.ntiles = p.ntiles;
+    g.M = p.M; g.N = p.N; g.K = p.K; g.ep = p.ep; g.mtiles = p.mtiles; g.ntiles = p.ntiles;
     g.tail_first_tile = p.tail_first_tile; g.tail_split = p.tail_split; g.tail_ws = p.tail_ws;
     if (bn_fuse && gemm_tail_fixup_bn_eligible(g, tail_tiles)) {      // fix-up + BatchNorm finalize in one launch
       DIC_TRY(gemm_launch_tail_fixup_bn(g, tail_tiles, *bn_fuse, st));
@@ -1348,7 +1425,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias,
-                 const BnFuseArgs* bn_fuse, int* bn_fused, int act, int tail_ws_slabs) {
+                 const BnFuseArgs* bn_fuse, int* bn_fused, int act, int tail_ws_slabs, int fmt, float out_scale) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
   Bf3Params p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -1358,6 +1435,8 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.B.kind = OPK_ROWK; p.B.ld = d.K(); p.B.paired = 1;
   p.ep = ep_store(y, d.CO, bias, act);
   p.ep.stats = bn_partial;
+  p.fmt = fmt;
+  if (fmt == 1) p.ep.alpha = out_scale;      // 1 / (activation scale * weight scale): the f16x2 planes hold scaled values
   if (bn_fused) *bn_fused = 0;
   DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
@@ -1384,7 +1463,8 @@ bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs) {
 
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
-                       int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused) {
+                       int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused, int fmt,
+                       float out_scale) {
   DIC_REQUIRE(raw && scale && shift && y && C % 32 == 0 && C <= kBnTabMax, "conv1x1_fwd_bf3_bn: C %% 32 == 0, C <= 2048");
   if ((long long)M * C * 4 >= (1ll << 32)) return 1;        // the kernel addresses the input with 32-bit byte offsets
   Bf3Params p{};
@@ -1395,6 +1475,8 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
   p.a_raw = raw; p.a_scale = scale; p.a_shift = shift; p.a_res = res; p.a_out = act_out; p.a_ld = C; p.a_relu = relu;
   p.ep = ep_store(y, CO, nullptr, ACT_NONE);
   p.ep.stats = bn_partial;
+  p.fmt = fmt;
+  if (fmt == 1) p.ep.alpha = out_scale;      // 1 / (kF16ActScale * weight scale): the producer waves scale the activations by kF16ActScale
   if (bn_fused) *bn_fused = 0;
   const int rc = launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs);
   if (rc != DIC_OK) return rc;
@@ -1574,6 +1656,15 @@ int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* h
   return DIC_OK;
 }
 
+int split_f16x2_paired(const float* x, long long rows, int K, float scale, unsigned short* h1, unsigned short* h2, hipStream_t st) {
+  DIC_REQUIRE(K % 32 == 0 && rows > 0 && scale > 0.f, "split_f16x2_paired: K %% 32, scale > 0");
+  const long long n4 = ((rows + 1) >> 1) * (K / 2);
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256, 8192);
+  hipLaunchKernelGGL(split_f16x2_paired_kernel, dim3(blocks), dim3(256), 0, st, x, rows, K, scale, h1, h2);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st) {
   const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, st, x, n, hi, mid, lo);
@@ -1598,6 +1689,11 @@ int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi,
                             void* stream) {
   DIC_REQUIRE(x && hi && mid && lo && rows > 0 && K > 0, "split_bf16x3_paired: bad arguments");
   return split_bf16x3_paired(x, rows, K, hi, mid, lo, (hipStream_t)stream);
+}
+
+int dic_split_f16x2_paired(const float* x, long long rows, int K, float scale, uint16_t* h1, uint16_t* h2, void* stream) {
+  DIC_REQUIRE(x && h1 && h2 && rows > 0 && K > 0, "split_f16x2_paired: bad arguments");
+  return split_f16x2_paired(x, rows, K, scale, h1, h2, (hipStream_t)stream);
 }
 
 static int gemm_bf16x3_any(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,

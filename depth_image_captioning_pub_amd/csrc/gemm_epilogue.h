@@ -39,7 +39,8 @@ __device__ __forceinline__ void gemm_epilogue(const P& p, f32x16 (&acc)[BM / 64]
   // code with one row pointer per register group.  The generic per-element path below is ~1700 instructions per tile
   // and dominated the short-K launches (K = 64: 137 us with it, 40 us without any epilogue).
   const bool fast = p.splitk == 1 && !p.ep.row_map && !p.ep.C2 && p.ep.act == ACT_NONE &&
-                    p.ep.alpha == 1.0f && (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+                    (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+  const float alpha = p.ep.alpha;       // (1 except for the f16x2 operand format: a power of two, exact)
   if (fast) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -58,7 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(const P& p, f32x16 (&acc)[BM / 64]
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = acc[i][j][r] + b + old[r];
+          const float v = fmaf(acc[i][j][r], alpha, b) + old[r];
           col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = v;
           cs[j] += v;
           cs2[j] += v * v;

@@ -274,6 +274,11 @@ int dic_split_bf16x3(const float* x, long long n, uint16_t* hi, uint16_t* mid, u
  * ((rows+1) & ~1) * K elements (a zero row pads an odd count). */
 int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi, uint16_t* mid, uint16_t* lo,
                             void* stream);
+/* "f16x2" operand format of the same kernels: two fp16 planes h1 + h2 of scale * x in the same row-pair layout (h1 = rn(scale*x),
+ * h2 = rn(scale*x - h1); scale a power of two that puts the largest magnitude of x below 65504 - 2^14 <= max < 2^15 for weights,
+ * a fixed 4 for activations) and three matrix-core products instead of six: a few fp32 round-offs per product instead of one, half
+ * the matrix-core work.  Used by the frozen ResNet forward (conv mode 2, dic_resnet_fwd). */
+int dic_split_f16x2_paired(const float* x, long long rows, int K, float scale, uint16_t* h1, uint16_t* h2, void* stream);
 int dic_gemm_bf16x3_paired(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                            const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, float* C, long long ldc,
                            const float* bias, void* stream);

@@ -15,8 +15,11 @@ from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr  # noqa: 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--switches", default="", help="comma-separated dic_debug_force_staged_gemm codes")
 a = ap.parse_args()
 lib = _lib.load()
+for code in filter(None, a.switches.split(",")):
+    assert lib.dic_debug_force_staged_gemm(int(code)) == 0, code
 DEV = "cuda:0"
 
 

@@ -2,6 +2,7 @@
 against torch CPU fp32 (the same ops the oracle is built from).  Tolerance: fp32 with a different
 summation order -> relative 2e-5 of the output scale."""
 import ctypes as C
+import math
 
 import pytest
 import torch
@@ -448,3 +449,97 @@ def test_conv1x1_with_on_the_fly_bn_operand(lib, M, Cin, CO, res, relu):
                                   1024, stream_ptr())
     torch.cuda.synchronize()
     assert rc == 1 and torch.isnan(y64).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["1x1 persistent", "1x1 persistent remainder", "3x3 halo", "3x3 gathered persistent", "1x1 64-wide", "3x3 64-wide strided",
+                                  "1x1 ragged"])
+def test_conv_f16x2_operand_format(lib, case):
+    """The two-term fp16 operand format (dic_split_f16x2_paired; three products h1*h1' + h1*h2' + h2*h1', epilogue unscale) on every
+    convolution kernel family of the ResNet forward, against an fp64 evaluation and beside the bf16x3 route on the same inputs: the
+    error may be a few times the bf16x3 one (2^-22 representation error per operand instead of an exact split) but must stay at
+    fp32-rounding level (< 4e-6 of the output scale; K up to 2304 here); BatchNorm partial sums agree with the stored output."""
+    B, H, W, Cin, CO, k, stride, pad = {"1x1 persistent": (64, 14, 14, 1024, 256, 1, 1, 0), "1x1 persistent remainder": (64, 14, 14, 256, 1024, 1, 1, 0),
+                                        "3x3 halo": (64, 14, 14, 256, 256, 3, 1, 1), "3x3 gathered persistent": (64, 28, 28, 128, 128, 3, 1, 1),
+                                        "1x1 64-wide": (8, 14, 14, 512, 64, 1, 1, 0), "3x3 64-wide strided": (16, 28, 28, 128, 128, 3, 2, 1),
+                                        "1x1 ragged": (63, 14, 14, 512, 256, 1, 1, 0)}[case]
+    g = torch.Generator().manual_seed(len(case))
+    x = torch.relu(torch.randn(B, H, W, Cin, generator=g) * 1.5 + 0.3).to(DEV)         # post-ReLU-like activations
+    w = (torch.randn(CO, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = B * OH * OW
+    ref64 = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(M, CO)
+    sc = float(ref64.abs().max())
+
+    def planes(ps):
+        return (C.c_void_p * 3)(*[t.data_ptr() if t is not None else None for t in ps])
+
+    def split(x2d, fmt, scale=1.0):
+        R, K = x2d.shape
+        out = [torch.zeros((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3 - fmt)]
+        if fmt:
+            check(lib.dic_split_f16x2_paired(ptr(x2d), C.c_longlong(R), K, C.c_float(scale), ptr(out[0]), ptr(out[1]), stream_ptr()), "split f16x2")
+            out.append(None)
+        else:
+            check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+        return out
+
+    tail = torch.empty(256 * 64 * 64, device=DEV)
+    w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
+    errs = {}
+    for fmt in (0, 1):
+        xp = split(x.reshape(B * H * W, Cin), fmt, 4.0)
+        wp = split(w.reshape(CO, k * k * Cin), fmt, w_scale)
+        y = torch.full((M, CO), float("nan"), device=DEV)
+        part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+        mt = C.c_int(0)
+        check(lib.dic_debug_conv_fmt(planes(xp), B, H, W, Cin, planes(wp), CO, k, stride, pad, ptr(y), ptr(part), C.byref(mt), ptr(tail), fmt,
+                                     C.c_float(1.0 / (4.0 * w_scale)), stream_ptr()), "dic_debug_conv_fmt")
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+        yd = y.double().cpu()
+        errs[fmt] = float((yd - ref64).abs().max()) / sc
+        stats = part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu()
+        assert torch.allclose(stats[0], yd.sum(0), rtol=1e-5, atol=1e-4 * sc) and torch.allclose(stats[1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * sc)
+    print(f"\n{case}: max err / scale vs fp64: bf16x3 {errs[0]:.2e}, f16x2 {errs[1]:.2e}")
+    assert errs[0] < 2e-6 and errs[1] < 4e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Cin,CO,res", [(12544, 1024, 256, True), (12544, 256, 1024, False), (12500, 512, 256, True)])
+def test_conv1x1_on_the_fly_operand_f16x2(lib, M, Cin, CO, res):
+    """conv1x1_fwd_bf3_bn in the f16x2 format: the producer waves scale the activation by 4 and write two fp16 planes; against fp64 and
+    against the plane route of the same format (dic_split_f16x2_paired of the torch-evaluated activation)."""
+    g = torch.Generator().manual_seed(M + Cin + 1)
+    raw = torch.randn(M, Cin, generator=g).to(DEV)
+    scale = (torch.rand(Cin, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cin, generator=g) * 0.3).to(DEV)
+    resid = torch.randn(M, Cin, generator=g).to(DEV) if res else None
+    w = (torch.randn(CO, Cin, generator=g) / Cin ** 0.5).to(DEV)
+    act = torch.addcmul(shift, raw, scale)
+    if res:
+        act = act + resid
+    act = torch.relu(act)
+    w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
+    wp = [torch.zeros((CO + 1) // 2 * 2 * Cin, dtype=torch.int16, device=DEV) for _ in range(2)]
+    check(lib.dic_split_f16x2_paired(ptr(w), C.c_longlong(CO), Cin, C.c_float(w_scale), ptr(wp[0]), ptr(wp[1]), stream_ptr()), "split w")
+    wpl = (C.c_void_p * 3)(wp[0].data_ptr(), wp[1].data_ptr(), None)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    y = torch.full((M, CO), float("nan"), device=DEV)
+    a_out = torch.full((M, Cin), float("nan"), device=DEV)
+    part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+    mt = C.c_int(0)
+    rc = lib.dic_debug_conv1x1_bn_fmt(ptr(raw), ptr(scale), ptr(shift), ptr(resid), 1, ptr(a_out), M, Cin, wpl, CO, ptr(y), ptr(part), C.byref(mt),
+                                      ptr(tail), 1024, 1, C.c_float(1.0 / (4.0 * w_scale)), stream_ptr())
+    assert rc == 0, (rc, lib.dic_last_error())
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert float((a_out - act).abs().max()) <= 1e-6 * float(act.abs().max())
+    ref64 = act.double().cpu() @ w.double().cpu().t()
+    sc = float(ref64.abs().max())
+    err = float((y.double().cpu() - ref64).abs().max()) / sc
+    print(f"\n{M}x{CO}x{Cin} f16x2 on-the-fly operand: max err / scale vs fp64 {err:.2e}")
+    assert err < 4e-6
+    yd = y.double().cpu()
+    stats = part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu()
+    assert torch.allclose(stats[0], yd.sum(0), rtol=1e-5, atol=1e-4 * sc) and torch.allclose(stats[1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * sc)
