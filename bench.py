@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", choices=["fp32", "bf16x3"], default="bf16x3",
+    ap.add_argument("--conv-mode", choices=["fp32", "bf16x3", "f16x2"], default="bf16x3",
                     help="ResNet convolutions: exact-fp32 MFMA, or the fp32-accurate split-bf16 (hi+mid+lo, 6 products) "
                          "path whose error vs fp64 is <= the exact-fp32 kernel's (tests/test_gemm_gpu.py, test_encoders_gpu.py)")
     ap.add_argument("--no-alt-mode", action="store_true",
@@ -456,7 +456,7 @@ def main():
     # ---- same workload with the other convolution arithmetic (short run: 2 warm-up + 5 timed steps) ----
     alt = None
     if not args.no_alt_mode:
-        alt_mode = "fp32" if args.conv_mode == "bf16x3" else "bf16x3"
+        alt_mode = "fp32" if args.conv_mode == "bf16x3" else "bf16x3"      # (f16x2 is shown next to bf16x3)
         del trainer
         torch.cuda.empty_cache()
         tr2 = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=alt_mode, hard=args.hard)

@@ -44,7 +44,7 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
  * kernels side by side; every other code (ablations, parked kernels) exists only in the experiments build. */
 int dic_debug_force_staged_gemm(int on) {
   if (gemm_bf3_force_tile(on) == 0) return 0;
-  if (on >= 100 && on <= 103) { dic::resnet_fuse_bn_operand(on - 100); return 0; }
+  if (on >= 100 && on <= 104) { dic::resnet_fuse_bn_operand(on == 104 ? -1 : on - 100); return 0; }
 #ifdef DIC_EXPERIMENTS
   if (on == 140 || on == 141) { dic::decoder_debug_persistent(on - 140); return 0; }          // decoder forward: per-step launches / persistent loop
   if (on == 142 || on == 143) { dic::decoder_persist_debug_placement(on - 142); return 0; }   // persistent loop: workgroup placement

@@ -182,11 +182,11 @@ struct RnWs {
 static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov) {
   Carver c(p, bytes);
   RnWs w{};
-  for (int i = 0; i < (mode == 1 ? 6 : 4); ++i) w.act[i] = c.take<float>(pl.max_act);
-  if (mode == 1)
+  for (int i = 0; i < (mode >= 1 ? 6 : 4); ++i) w.act[i] = c.take<float>(pl.max_act);
+  if (mode >= 1)
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) w.planes[i][j] = c.take<unsigned short>(pl.max_act + 2048);   // + one pad row (paired layout)
-  if (mode == 1)
+  if (mode >= 1)
     for (int j = 0; j < 3; ++j) w.stem_planes[j] = c.take<unsigned short>(conv_stem_bf3_plane_elems(pl.B, pl.H, pl.W));
   w.partial = c.take<float>(pl.max_partial);
   w.red = c.take<double>(pl.max_red);
@@ -226,7 +226,7 @@ void resnet_debug_fused_tail_bn(int on) { if (on >= 2) g_strip_stem = on - 2; el
 
 // conv (bf16x3 planes in, raw fp32 out) -> BN scale/shift
 static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, const dic_conv_bn_layer& L, float* y,
-                       const RnWs& ws, int train_bn, hipStream_t st, const BnBuf* bn_out = nullptr) {
+                       const RnWs& ws, int train_bn, hipStream_t st, const BnBuf* bn_out = nullptr, int fmt = 0) {
   const BnBuf bn = bn_out ? *bn_out : ws.bn;
   int mtiles = 0;
   const unsigned short* xp[3] = {x_planes[0], x_planes[1], x_planes[2]};
@@ -235,7 +235,8 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
   const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
                       (double)d.M(), kBnEps, kBnMomentum};
   DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st, nullptr,
-                       (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, ACT_NONE, kResnetTailSlabs));
+                       (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, ACT_NONE, kResnetTailSlabs, fmt,
+                       fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f));
   if (train_bn && fused) return DIC_OK;        // statistics were finalized inside the tail fix-up launch
   if (train_bn)
     return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn,
@@ -247,14 +248,15 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
 // gemm_bf3.hip) -> raw fp32 out + BN scale/shift in `bn`.  Returns 1 when the launch policy keeps the shape off that kernel (nothing
 // launched, nothing written).
 static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* res, float* act_out, const ConvDesc& d,
-                             const dic_conv_bn_layer& L, float* y, const RnWs& ws, int train_bn, hipStream_t st, const BnBuf& bn) {
+                             const dic_conv_bn_layer& L, float* y, const RnWs& ws, int train_bn, hipStream_t st, const BnBuf& bn, int fmt) {
   if (!(d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && d.C <= 2048)) return 1;
   int mtiles = 0, fused = 0;
   const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
   const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
                       (double)d.M(), kBnEps, kBnMomentum};
   const int rc = conv1x1_fwd_bf3_bn(raw, in_bn.scale, in_bn.shift, res, 1, act_out, d.M(), d.C, wp, d.CO, y, train_bn ? ws.partial : nullptr,
-                                    &mtiles, ws.tail, kResnetTailSlabs, st, (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused);
+                                    &mtiles, ws.tail, kResnetTailSlabs, st, (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, fmt,
+                                    fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f);
   if (rc != DIC_OK) return rc;
   if (train_bn && fused) return DIC_OK;
   if (train_bn)
@@ -264,8 +266,9 @@ static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* 
 
 // which BatchNorm-apply passes are folded into the consuming 1x1 convolution (codes 100..103 of dic_debug_force_staged_gemm):
 // bit 0 = the block output (relu(bn3(conv3) + identity), consumed by the next block's conv1), bit 1 = conv2's output (consumed by conv3)
-static int g_fuse_bn_operand = 3;
-void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand = mask & 3; }
+static int g_fuse_bn_operand_switch = -1;      // -1 (code 104, default): by operand format - both for bf16x3; block outputs only for f16x2, where the
+                                               // matrix-core work per K tile is halved and conv3's eightfold re-transform of its input no longer hides
+void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand_switch = mask < 0 ? -1 : (mask & 3); }
 
 // ResNet forward with the bf16x3 convolution.  A convolution reads either three bf16 planes (written by a bn_apply_planes pass; the 3x3
 // and strided layers need that form) or - the stride-1 1x1 layers on the persistent kernel - the raw fp32 output of the layer before
@@ -276,14 +279,21 @@ void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand = mask & 3; }
 //   conv3:          relu(bn2(raw2)) on the fly
 // and only the last block of a stage materialises its output as planes (the next stage's strided downsample conv reads them).
 static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, const float* imgs_nchw, int B, int train_bn,
-                          float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st, int pool_out) {
+                          float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st, int pool_out, int fmt) {
+  const int g_fuse_bn_operand = g_fuse_bn_operand_switch >= 0 ? g_fuse_bn_operand_switch : (fmt ? 1 : 3);
   size_t ci = 0;
   float *R2 = ws.act[0], *R3 = ws.act[1], *R1 = ws.act[2], *Cf = ws.act[3];
   float* const IN[2] = {ws.act[4], ws.act[5]};
   float* const X = ws.act[0];             // fp32 copy of the final map for the pooling (R2 is dead by then)
-  unsigned short* const* Xp = ws.planes[0];
-  unsigned short* const* P1 = ws.planes[1];
-  unsigned short* const* P2 = ws.planes[2];
+  // fmt 1 (f16x2, gemm_bf3.hip): activation plane sets have two planes, the third pointer is NULL - which is also how the kernels
+  // that WRITE planes (bn_apply_planes, bn_relu_maxpool) are told the format.  Those planes are not an exact image of the fp32
+  // values, so an identity always travels as fp32 in that mode.
+  unsigned short* pset[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) pset[i][j] = (fmt && j == 2) ? nullptr : ws.planes[i][j];
+  unsigned short* const* Xp = pset[0];
+  unsigned short* const* P1 = pset[1];
+  unsigned short* const* P2 = pset[2];
   {   // stem (C_in = 3, 1 % of the FLOPs): exact-fp32 gather kernel, then BN + ReLU + maxpool, then split into planes
     const RnConv& c = pl.convs[ci++];
     const dic_conv_bn_layer& L0 = layers[c.layer];
@@ -305,36 +315,38 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
   for (int s = 0; s < 4; ++s) {
     bool pending = false;                  // the block input is not materialised: it is relu(bn3(R3) + pend_res)
     const float* pend_res = nullptr;
+    const float* in32_carry = nullptr;     // fp32 copy of the block input written by the previous block's output pass
     for (int b = 0; b < blocks[s]; ++b) {
       const RnConv& c1 = pl.convs[ci++];
       const RnConv& c2 = pl.convs[ci++];
       const RnConv& c3 = pl.convs[ci++];
-      const float* in32 = nullptr;         // the block input as fp32, when it exists (else it exists as planes Xp)
+      const float* in32 = in32_carry;      // the block input as fp32, when it exists (else it exists as exact bf16x3 planes Xp)
+      in32_carry = nullptr;
       if (pending) {
         float* in_b = IN[b & 1];
-        int rc = conv_bn_bf3_fused(R3, ws.bn3, pend_res, in_b, c1.d, layers[c1.layer], R1, ws, train_bn, st, ws.bn);
+        int rc = conv_bn_bf3_fused(R3, ws.bn3, pend_res, in_b, c1.d, layers[c1.layer], R1, ws, train_bn, st, ws.bn, fmt);
         if (rc == 1) {                      // shape not on the persistent kernel: form the input as planes (+ fp32) after all
           DIC_BN_APPLY_PLANES_OUT(R3, pend_res, nullptr, in_b, Xp, c1.d.M(), c1.d.C, ws.bn3, 1, st);
-          rc = conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st);
+          rc = conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st, nullptr, fmt);
         }
         DIC_TRY(rc);
         in32 = in_b;
       } else {
-        DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st));
+        DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st, nullptr, fmt));
       }
       DIC_BN_APPLY_PLANES(R1, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st);
-      DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], R2, ws, train_bn, st, &ws.bn2));
+      DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], R2, ws, train_bn, st, &ws.bn2, fmt));
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
         // downsample branch: raw output + its own statistics; its BatchNorm is applied where the block output is formed
-        DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st, &ws.bn_ds));
+        DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st, &ws.bn_ds, fmt));
       }
       {
-        int rc = (g_fuse_bn_operand & 2) ? conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3)
+        int rc = (g_fuse_bn_operand & 2) ? conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3, fmt)
                                          : 1;
         if (rc == 1) {
           DIC_BN_APPLY_PLANES(R2, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn2, 1, st);
-          rc = conv_bn_bf3(P2, c3.d, layers[c3.layer], R3, ws, train_bn, st, &ws.bn3);
+          rc = conv_bn_bf3(P2, c3.d, layers[c3.layer], R3, ws, train_bn, st, &ws.bn3, fmt);
         }
         DIC_TRY(rc);
       }
@@ -356,8 +368,11 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       const float* identity = b == 0 ? Cf : in32;
       const unsigned short* idp[3] = {Xp[0], Xp[1], Xp[2]};
       // planes into P1 (free again); only the very last block also writes fp32, for the pooling that follows
-      // (pool_out == 0: the final map itself is the output, written in place of the fp32 copy)
-      DIC_BN_APPLY_PLANES_OUT(R3, identity, identity ? nullptr : idp, last ? (pool_out == 0 ? features : X) : nullptr, P1, c3.d.M(), c3.d.CO,
+      // (pool_out == 0: the final map itself is the output, written in place of the fp32 copy) - and, in the f16x2 format, a block
+      // whose successor in the stage takes it as identity (those planes are not exact)
+      float* y32 = last ? (pool_out == 0 ? features : X) : nullptr;
+      if (fmt && b + 1 < blocks[s]) { y32 = IN[(b + 1) & 1]; in32_carry = y32; }
+      DIC_BN_APPLY_PLANES_OUT(R3, identity, identity ? nullptr : idp, y32, P1, c3.d.M(), c3.d.CO,
                               ws.bn3, 1, st, b == 0 ? &ws.bn_ds : nullptr);
       std::swap(Xp, P1);
     }
@@ -601,13 +616,16 @@ static int resnet_fwd_impl(const dic_conv_bn_layer* layers, int n_layers, const 
   DIC_REQUIRE(B > 0 && H >= 32 && W >= 32, "resnet_fwd: bad input size");
   const RnPlan pl = resnet_plan(B, H, W, blocks);
   bool ov = false;
-  DIC_REQUIRE(mode == 0 || mode == 1, "resnet_fwd: mode must be 0 (exact-fp32 MFMA) or 1 (bf16x3 split MFMA)");
+  DIC_REQUIRE(mode >= 0 && mode <= 2, "resnet_fwd: mode must be 0 (exact-fp32 MFMA), 1 (bf16x3 split MFMA) or 2 (f16x2 split MFMA)");
   RnWs ws = rn_carve(workspace, workspace_bytes, pl, mode, &ov);
   DIC_REQUIRE(!ov, "resnet_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
-  if (mode == 1) {
-    for (int i = 1; i < n_layers; ++i)
-      DIC_REQUIRE(layers[i].w_hi && layers[i].w_mid && layers[i].w_lo, "resnet_fwd: bf16x3 mode needs split weights");
-    return resnet_fwd_bf3(layers, blocks, imgs_nchw, B, train_bn, features, pl, ws, st, pool_out);
+  if (mode >= 1) {
+    for (int i = 1; i < n_layers; ++i) {
+      DIC_REQUIRE(layers[i].w_hi && layers[i].w_mid, "resnet_fwd: split-operand modes need split weights");
+      if (mode == 1) DIC_REQUIRE(layers[i].w_lo, "resnet_fwd: bf16x3 mode needs three weight planes");
+      else DIC_REQUIRE(layers[i].w_scale > 0.f, "resnet_fwd: f16x2 mode needs the scale of the weight planes (layer %d)", i);
+    }
+    return resnet_fwd_bf3(layers, blocks, imgs_nchw, B, train_bn, features, pl, ws, st, pool_out, mode == 2);
   }
 
   size_t ci = 0;

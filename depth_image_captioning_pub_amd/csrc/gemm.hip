@@ -568,6 +568,7 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
         float v = x[0];
 #pragma unroll
         for (int u = 1; u < NS; ++u) v += x[u];
+        v *= p.ep.alpha;         // as finalize_store (1, or the exact power-of-two unscale of the f16x2 operand format)
         if (tm * 64 + row < p.M) { a += (double)v; b += (double)v * (double)v; }
       }
     }

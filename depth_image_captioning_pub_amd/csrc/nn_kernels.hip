@@ -267,9 +267,16 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
       }
     }
     unsigned short h[8], m[8], l[8];
+#define DIC_PK(A_, Q_) ((unsigned)A_[Q_] | ((unsigned)A_[Q_ + 1] << 16))
+    if (!lo) {      // f16x2 format (gemm_bf3.hip): two fp16 planes of kF16ActScale * v
+#pragma unroll
+      for (int q = 0; q < 8; ++q) split2_f16(v[q], kF16ActScale, h[q], m[q]);
+      reinterpret_cast<uint4*>(hi)[i] = make_uint4(DIC_PK(h, 0), DIC_PK(h, 2), DIC_PK(h, 4), DIC_PK(h, 6));
+      reinterpret_cast<uint4*>(mid)[i] = make_uint4(DIC_PK(m, 0), DIC_PK(m, 2), DIC_PK(m, 4), DIC_PK(m, 6));
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) split3_bf16(v[q], h[q], m[q], l[q]);
-#define DIC_PK(A_, Q_) ((unsigned)A_[Q_] | ((unsigned)A_[Q_ + 1] << 16))
     reinterpret_cast<uint4*>(hi)[i] = make_uint4(DIC_PK(h, 0), DIC_PK(h, 2), DIC_PK(h, 4), DIC_PK(h, 6));
     reinterpret_cast<uint4*>(mid)[i] = make_uint4(DIC_PK(m, 0), DIC_PK(m, 2), DIC_PK(m, 4), DIC_PK(m, 6));
     reinterpret_cast<uint4*>(lo)[i] = make_uint4(DIC_PK(l, 0), DIC_PK(l, 2), DIC_PK(l, 4), DIC_PK(l, 6));
@@ -283,6 +290,7 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
   DIC_REQUIRE(!residual_bn || residual, "bn_apply_planes: residual_bn needs an fp32 residual");
   DIC_REQUIRE(!(residual && residual_planes), "bn_apply_planes: give the residual as fp32 or as planes, not both");
   DIC_REQUIRE(C % 32 == 0, "bn_apply_planes: C %% 32");
+  DIC_REQUIRE(planes[2] || !residual_planes, "bn_apply_planes: f16x2 planes (planes[2] == NULL) are not exact - the residual must be fp32");
   const long long n4 = ((rows + 1) >> 1) * (C / 4);      // threads (8 channels each)
   const unsigned short* r0 = residual_planes ? residual_planes[0] : nullptr;
   const unsigned short* r1 = residual_planes ? residual_planes[1] : nullptr;
@@ -341,11 +349,16 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
       const long long row = i / C4;
       const long long off = plane_offset(row, c4 * 4, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
-      split3_bf16(best.x, h[0], m[0], l[0]); split3_bf16(best.y, h[1], m[1], l[1]);
-      split3_bf16(best.z, h[2], m[2], l[2]); split3_bf16(best.w, h[3], m[3], l[3]);
+      if (!lo) {    // f16x2 format: two fp16 planes of kF16ActScale * v
+        split2_f16(best.x, kF16ActScale, h[0], m[0]); split2_f16(best.y, kF16ActScale, h[1], m[1]);
+        split2_f16(best.z, kF16ActScale, h[2], m[2]); split2_f16(best.w, kF16ActScale, h[3], m[3]);
+      } else {
+        split3_bf16(best.x, h[0], m[0], l[0]); split3_bf16(best.y, h[1], m[1], l[1]);
+        split3_bf16(best.z, h[2], m[2], l[2]); split3_bf16(best.w, h[3], m[3], l[3]);
+      }
       *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
       *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-      *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+      if (lo) *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
     }
   }
 }

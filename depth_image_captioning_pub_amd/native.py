@@ -346,10 +346,10 @@ def depth_encoder_decisions(tape: DepthTape) -> Dict[str, torch.Tensor]:
 # RGB encoder (dic_resnet_fwd)
 # ---------------------------------------------------------------------------------------------
 class ConvBnLayer(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f in ("w", "gamma", "beta", "running_mean", "running_var", "w_hi", "w_mid", "w_lo")]
+    _fields_ = [(f, C.c_void_p) for f in ("w", "gamma", "beta", "running_mean", "running_var", "w_hi", "w_mid", "w_lo")] + [("w_scale", C.c_float)]
 
 
-CONV_MODES = {"fp32": 0, "bf16x3": 1}
+CONV_MODES = {"fp32": 0, "bf16x3": 1, "f16x2": 2}
 
 
 class ResNetRunner:
@@ -358,7 +358,10 @@ class ResNetRunner:
 
     def __init__(self, tensors: Dict[str, torch.Tensor], layers: Sequence[int] = (3, 8, 36, 3), conv_mode: str = "fp32"):
         """conv_mode "fp32": exact-fp32 MFMA convolutions; "bf16x3": fp32-accurate split-bf16 convolutions
-        (each fp32 weight/activation = hi+mid+lo bf16 exactly, 6 products; csrc/gemm_bf3.hip)."""
+        (each fp32 weight/activation = hi+mid+lo bf16 exactly, 6 products; csrc/gemm_bf3.hip); "f16x2": the same kernels on two
+        fp16 planes of scaled values (3 products: half the matrix-core work, a few fp32 round-offs per product - inside the error
+        envelope of an fp32 evaluation of the network; weights scaled per layer so that their largest magnitude lands in
+        [2^14, 2^15), activations by 4)."""
         from .synthetic import resnet152_spec
         lib = _lib.load()
         if conv_mode not in CONV_MODES:
@@ -381,7 +384,7 @@ class ResNetRunner:
             ent = self.table[i]
             ent.w = w_ohwi.data_ptr()
             tens = [w, w_ohwi]
-            if self.mode == 1 and i == 0 and (co, ci, k) == (64, 3, 7):
+            if self.mode >= 1 and i == 0 and (co, ci, k) == (64, 3, 7):
                 # 7x7 stem: strip-ordered weight planes [64][7][8][4] for the bf16x3 kernel (dic_resnet_pack_stem_weights)
                 scratch = torch.empty(64 * 224, dtype=torch.float32, device=w.device)
                 planes = [torch.empty(64 * 224, dtype=torch.int16, device=w.device) for _ in range(3)]
@@ -395,6 +398,17 @@ class ResNetRunner:
                                                   ptr(planes[1]), ptr(planes[2]), stream_ptr()),
                       "dic_split_bf16x3_paired")
                 ent.w_hi, ent.w_mid, ent.w_lo = (pl.data_ptr() for pl in planes)
+                tens += planes
+            if self.mode == 2 and i > 0:
+                import math
+                wmax = float(w_ohwi.abs().max())
+                if not (wmax > 0.0 and math.isfinite(wmax)):
+                    raise _lib.DicError(f"{key}: f16x2 mode needs finite, non-zero weights")
+                scale = 2.0 ** math.floor(14 - math.log2(wmax))
+                planes = [torch.empty(w_ohwi.numel(), dtype=torch.int16, device=w_ohwi.device) for _ in range(2)]
+                check(lib.dic_split_f16x2_paired(ptr(w_ohwi), C.c_longlong(co), ci * k * k, C.c_float(scale), ptr(planes[0]),
+                                                 ptr(planes[1]), stream_ptr()), "dic_split_f16x2_paired")
+                ent.w_hi, ent.w_mid, ent.w_lo, ent.w_scale = planes[0].data_ptr(), planes[1].data_ptr(), None, scale
                 tens += planes
             for field, name in (("gamma", "weight"), ("beta", "bias"), ("running_mean", "running_mean"),
                                 ("running_var", "running_var")):

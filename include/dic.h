@@ -240,7 +240,11 @@ typedef struct dic_conv_bn_layer {
   const float* w;                 /* [CO][KH][KW][CI] */
   const float *gamma, *beta;
   float *running_mean, *running_var;
-  const uint16_t *w_hi, *w_mid, *w_lo;   /* mode 1 only: dic_split_bf16x3_paired(w as [CO rows][KH*KW*C]); else NULL */
+  const uint16_t *w_hi, *w_mid, *w_lo;   /* mode 1: dic_split_bf16x3_paired(w as [CO rows][KH*KW*C]); mode 2: w_hi, w_mid = the two
+                                          * planes of dic_split_f16x2_paired(w, scale = w_scale), w_lo NULL (layer 0, the stem, keeps its
+                                          * bf16x3 strip planes in both modes); mode 0: NULL */
+  float w_scale;                         /* mode 2 only: the power of two the weight planes were scaled by (largest |w| * w_scale in
+                                          * [2^14, 2^15)) */
 } dic_conv_bn_layer;
 
 int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream);
@@ -256,7 +260,10 @@ size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mo
  * (encoder.train() at depth_train.py:161: batch statistics + running-stat updates in the frozen net);
  * train_bn=0 is encoder.eval() (depth_train.py:242).
  * mode 0: exact-fp32 MFMA convolutions; mode 1: fp32-accurate bf16x3 split convolutions (csrc/gemm_bf3.hip; every
- * layer but the C_in=3 stem), same results to fp32 rounding level, ~1.4x the conv throughput at batch 64. */
+ * layer but the C_in=3 stem), same results to fp32 rounding level, ~1.4x the conv throughput at batch 64; mode 2: the same
+ * kernels on the f16x2 operand format (two fp16 planes of scaled values, three products; dic_split_f16x2_paired): errors of a few
+ * fp32 round-offs per product, inside the envelope of an fp32 evaluation of the network (tests/test_encoders_gpu.py), half the
+ * matrix-core work.  Activations are scaled by 4: an activation beyond +-16376 turns the output into inf/NaN. */
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
                    int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
                    void* stream);
@@ -363,8 +370,9 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
  *   76           accepted, no effect (the persistent kernel's only form here is the warp-specialised one)
  *   90 91        remainder-round K split of the persistent kernels: off / on (default)
- *   100..103     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
- *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both (default)
+ *   100..104     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
+ *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both / by operand
+ *                format (default: both in mode 1, block outputs only in mode 2)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
  * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes

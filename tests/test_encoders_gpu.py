@@ -164,7 +164,7 @@ def test_depth_encoder_eval_mode(lib):
         assert torch.equal(st_dev[k].cpu(), st[k]), "eval mode must not touch the running statistics"
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("layers,B,size,train", [((1, 1, 1, 1), 2, 64, True), ((1, 1, 1, 1), 2, 64, False),
                                                   ((2, 1, 2, 1), 3, 96, True)])
 def test_resnet_small_stacks(lib, layers, B, size, train, mode):
@@ -192,7 +192,7 @@ def test_resnet_small_stacks(lib, layers, B, size, train, mode):
                 assert torch.equal(wd[k].cpu(), w[k])
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "f16x2"])
 def test_resnet152_full_depth(lib, mode):
     """All 155 conv+BN layers at 224x224 (B=2), batch-statistics mode (quirk Q1).  fp32 rounding is amplified by
     152 layers of batch-statistics BatchNorm over a 2-image batch, so the yardstick is an fp64 evaluation of the
@@ -236,7 +236,7 @@ def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(
                 assert torch.equal(results[code][0], y) and torch.equal(results[code][1], stats), "switch 103 does not reproduce itself"
             results[code] = (y.clone(), stats.clone())
     finally:
-        lib.dic_debug_force_staged_gemm(103)
+        lib.dic_debug_force_staged_gemm(104)
     y0, s0 = results[100]
     scale = float(y0.abs().max())
     for code in (101, 102, 103):

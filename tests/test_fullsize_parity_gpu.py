@@ -79,7 +79,7 @@ def _inputs(B):
     return o
 
 
-@pytest.mark.parametrize("conv_mode,compact", [("bf16x3", True), ("bf16x3", False), ("fp32", True), ("fp32", False)])
+@pytest.mark.parametrize("conv_mode,compact", [("f16x2", True), ("bf16x3", True), ("bf16x3", False), ("fp32", True), ("fp32", False)])
 @pytest.mark.parametrize("B", [32, 64])
 def test_full_size_step_vs_oracle(lib, B, conv_mode, compact):
     o = _inputs(B)
