@@ -19,8 +19,9 @@ processes --batch images per step (default 64 = BASELINE.json configs[1]); value
 
 The JSON line also carries
   roofline     - the contraction kernel instantiation with the largest total time (per-launch HIP events on the
-                 launch stream, algorithmic FLOPs / measured time; peak = 2.5 PFLOP/s dense bf16 MFMA / 6 products per
-                 fp32-equivalent multiply-add = 416.7 TFLOP/s for the split-bf16 kernels, 157.3 TFLOP/s for the exact-fp32 MFMA kernels),
+                 launch stream, algorithmic FLOPs / measured time; peak = 2.5 PFLOP/s dense fp16 / bf16 MFMA divided by the
+                 matrix-core products per fp32-equivalent multiply-add: 3 for the f16x2 operand format (833.3 TFLOP/s), 6 for
+                 bf16x3 (416.7 TFLOP/s); 157.3 TFLOP/s for the exact-fp32 MFMA kernels),
   cpu_baseline - the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample,
   parity       - same-run parity gate: the first oracle step of the cpu_baseline leg (initial weights,
                  batch --cpu-batch, explicit dropout mask) against one GPU step on the same tensors: |loss difference|
@@ -48,6 +49,7 @@ KIND_NAMES = {0: "rowk", 1: "colk", 2: "im2col", 3: "gather", 4: "im2col_colk", 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA (= vector fp32 peak)
 PEAK_HBM_TBS = 8.0
 PEAK_BF16X3_TFLOPS = 2500.0 / 6.0   # dense bf16 MFMA peak / 6 bf16 products per fp32-equivalent multiply-add
+PEAK_F16X2_TFLOPS = 2500.0 / 3.0    # dense fp16 MFMA peak (= bf16) / 3 fp16 products per multiply-add of the f16x2 operand format
 
 
 def bytes_dec(B: int, T: int, V: int, L: int = 196) -> float:
@@ -72,22 +74,26 @@ def profile_step(trainer, args_step):
     rows = []
     for i in range(nout.value):
         k = keys[i]
-        if k >= 2000:                                   # split-bf16 convolution kernel (gemm_bf3.hip)
-            a, tcode = (k - 2000) // 10, (k - 2000) % 10
+        if k >= 2000:                                   # split-operand convolution kernel (gemm_bf3.hip): 2000 = bf16x3, 3000 = f16x2
+            f16 = k >= 3000
+            k -= 3000 if f16 else 2000
+            a, tcode = k // 10, k % 10
+            peak = PEAK_F16X2_TFLOPS if f16 else PEAK_BF16X3_TFLOPS
+            kind = "on-the-fly BatchNorm operand" if a == 6 else KIND_NAMES[a]
             if tcode >= 4:                                  # 128x128: persistent warp-specialised / LDS-halo 3x3 (4, 7, 8: parked forms, experiments library only)
-                name, rname = {4: (f"gemm_bf3_pipe_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_pipe_kernel<{a}, "),
-                               5: (f"gemm_bf3_persist_ws_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws_kernel<{a}"),
-                               6: ("conv3x3_bf3_halo_kernel", "conv3x3_bf3_halo_kernel<0>"),
-                               7: (f"gemm_bf3_persist_ws256_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_ws256_kernel<{a}"),
-                               8: (f"gemm_bf3_persist_kernel<{KIND_NAMES[a]}>", f"gemm_bf3_persist_kernel<{a}")}[tcode]
-                rows.append({"kernel": name, "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i],
-                             "peak": PEAK_BF16X3_TFLOPS})
+                name, rname = {4: (f"gemm_bf3_pipe_kernel<{kind}>", f"gemm_bf3_pipe_kernel<{a}, "),
+                               5: (f"gemm_bf3_persist_ws_kernel<{kind}>", f"gemm_bf3_persist_ws_kernel<{a}, 0, 3, {int(f16)}>"),
+                               6: ("conv3x3_bf3_halo_kernel", f"conv3x3_bf3_halo_kernel<0, {int(f16)}>"),
+                               7: (f"gemm_bf3_persist_ws256_kernel<{kind}>", f"gemm_bf3_persist_ws256_kernel<{a}"),
+                               8: (f"gemm_bf3_persist_kernel<{kind}>", f"gemm_bf3_persist_kernel<{a}")}[tcode]
+                rows.append({"kernel": name + (" [f16x2]" if f16 else ""), "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i],
+                             "flops": fl[i], "peak": peak})
                 continue
             tm, tn = 1 + tcode // 2, 1 + tcode % 2          # workgroup tile 64*tm x 64*tn
             tile = "" if (tm, tn) == (1, 1) else f",{64 * tm}x{64 * tn}"
-            rows.append({"kernel": f"gemm_bf3_kernel<{KIND_NAMES[a]}{tile}>",
-                         "rocprof_name": f"gemm_bf3_kernel<{a}, {tm}, {tn}, 2, 0>",
-                         "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "peak": PEAK_BF16X3_TFLOPS})
+            rows.append({"kernel": f"gemm_bf3_kernel<{kind}{tile}>" + (" [f16x2]" if f16 else ""),
+                         "rocprof_name": f"gemm_bf3_kernel<{a}, {tm}, {tn}, 2, 0, {int(f16)}>",
+                         "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "peak": peak})
             continue
         dma = k >= 1000
         k %= 1000
@@ -310,9 +316,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", choices=["fp32", "bf16x3", "f16x2"], default="bf16x3",
-                    help="ResNet convolutions: exact-fp32 MFMA, or the fp32-accurate split-bf16 (hi+mid+lo, 6 products) "
-                         "path whose error vs fp64 is <= the exact-fp32 kernel's (tests/test_gemm_gpu.py, test_encoders_gpu.py)")
+    ap.add_argument("--conv-mode", choices=["fp32", "bf16x3", "f16x2"], default="f16x2",
+                    help="ResNet convolutions: exact-fp32 MFMA; bf16x3 = exact three-way bf16 split, 6 matrix-core products; f16x2 "
+                         "(default) = two fp16 planes of scaled values, 3 products (2^-22 representation error per operand: the "
+                         "network's error against fp64 stays that of an fp32 evaluation - tests/test_gemm_gpu.py, "
+                         "test_encoders_gpu.py, test_fullsize_parity_gpu.py; the same-run parity gate below checks it again)")
     ap.add_argument("--no-alt-mode", action="store_true",
                     help="skip the short second measurement with the other ResNet convolution mode")
     ap.add_argument("--no-overlap", action="store_true",
@@ -456,7 +464,7 @@ def main():
     # ---- same workload with the other convolution arithmetic (short run: 2 warm-up + 5 timed steps) ----
     alt = None
     if not args.no_alt_mode:
-        alt_mode = "fp32" if args.conv_mode == "bf16x3" else "bf16x3"      # (f16x2 is shown next to bf16x3)
+        alt_mode = "fp32" if args.conv_mode == "bf16x3" else "bf16x3"      # (the default f16x2 is shown next to bf16x3)
         del trainer
         torch.cuda.empty_cache()
         tr2 = CaptionTrainer(VOCAB, device=dev, seed=123, process_group=pg, conv_mode=alt_mode, hard=args.hard)
@@ -485,7 +493,9 @@ def main():
         traffic, mfma_util = pmc_for(top["rocprof_name"], B)
         peak = top.get("peak", PEAK_F32_MFMA_TFLOPS)
         roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s" if peak == PEAK_F32_MFMA_TFLOPS else "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)",
+                    "unit": "TFLOP/s" if peak == PEAK_F32_MFMA_TFLOPS else
+                            "TFLOP/s (fp32-equivalent; peak = 2.5 PF fp16 / 3 products)" if peak == PEAK_F16X2_TFLOPS else
+                            "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)",
                     "frac": round(ach / peak, 4), "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic,
                     "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE x2 gfx950 "

@@ -1345,7 +1345,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   }
   if (p.a_raw && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) return 1;      // on-the-fly operand: persistent 1x1 kernel or nothing
   if (probe) return DIC_OK;                 // conv1x1_bf3_bn_eligible: the decision only
-  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, 2000 + p.A.kind * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, (p.fmt == 1 ? 3000 : 2000) + (p.a_raw ? OPK_ROWK_BN : p.A.kind) * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
   if (persist && (halo || !ws256) && (halo || g_bf3_ws) && g_bf3_ablate == 0) {      // the product's 128x128 kernels
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels

@@ -377,7 +377,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes
  * listed in csrc/api.hip and csrc/gemm_bf3.hip); scripts/ load it with DIC_LIB=experiments, the product never does.
- * bf16x3 key of dic_profile_end: 2000 + 10*A_kind + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,
+ * bf16x3 key of dic_profile_end: 2000 (f16x2 operand format: 3000) + 10*A_kind (6 = on-the-fly BatchNorm operand) + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,
  * 5 = persistent warp-specialised 128x128, 6 = LDS-halo 3x3 (experiments: 4 = deep-pipelined, 7 = 256x128, 8 = computing-wave DMA). */
 int dic_debug_force_staged_gemm(int on);
 /* Tuning knob (process-global): the persistent split-bf16 convolution kernels (one workgroup per CU, each walking several output

@@ -15,6 +15,7 @@ from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr  # noqa: 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--fmt", type=int, default=0, help="operand format: 0 = bf16x3, 1 = f16x2")
 ap.add_argument("--switches", default="", help="comma-separated dic_debug_force_staged_gemm codes")
 a = ap.parse_args()
 lib = _lib.load()
@@ -23,15 +24,19 @@ for code in filter(None, a.switches.split(",")):
 DEV = "cuda:0"
 
 
-def split(x2d):
+def split(x2d, scale=1.0):
     R, K = x2d.shape
-    out = [torch.empty((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3)]
-    check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
+    out = [torch.empty((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(3 - a.fmt)]
+    if a.fmt:
+        check(lib.dic_split_f16x2_paired(ptr(x2d), C.c_longlong(R), K, C.c_float(scale), ptr(out[0]), ptr(out[1]), stream_ptr()), "split")
+        out.append(None)
+    else:
+        check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
     return out
 
 
 def planes(ps):
-    return (C.c_void_p * 3)(*[t.data_ptr() for t in ps])
+    return (C.c_void_p * 3)(*[t.data_ptr() if t is not None else None for t in ps])
 
 
 def timeit(fn):
@@ -57,19 +62,20 @@ for name, M, Cin, CO in (("layer2 conv1", B * 784, 512, 128), ("layer2 conv3", B
     scale = torch.rand(Cin, device=DEV) + 0.5
     shift = torch.randn(Cin, device=DEV)
     w = torch.randn(CO, Cin, device=DEV) / Cin ** 0.5
-    wp, ap_ = split(w), split(raw)
+    wp, ap_ = split(w, 16384.0), split(raw, 4.0)
+    osc = C.c_float(1.0 / (4.0 * 16384.0))
     y = torch.empty(M, CO, device=DEV)
     part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
     tail = torch.empty(1024 * 64 * 64, device=DEV)
     mt = C.c_int(0)
 
     def plane_route():
-        check(lib.dic_debug_conv_bf3(planes(ap_), 1, 1, M, Cin, planes(wp), CO, 1, 1, 0, ptr(y), ptr(part), C.byref(mt), ptr(tail), stream_ptr()), "conv")
+        check(lib.dic_debug_conv_fmt(planes(ap_), 1, 1, M, Cin, planes(wp), CO, 1, 1, 0, ptr(y), ptr(part), C.byref(mt), ptr(tail), a.fmt, osc, stream_ptr()), "conv")
 
     def fused(r, o):
         def f():
-            rc = lib.dic_debug_conv1x1_bn(ptr(raw), ptr(scale), ptr(shift), ptr(res) if r else None, 1, ptr(out) if o else None, M, Cin, planes(wp),
-                                          CO, ptr(y), ptr(part), C.byref(mt), ptr(tail), 1024, stream_ptr())
+            rc = lib.dic_debug_conv1x1_bn_fmt(ptr(raw), ptr(scale), ptr(shift), ptr(res) if r else None, 1, ptr(out) if o else None, M, Cin, planes(wp),
+                                              CO, ptr(y), ptr(part), C.byref(mt), ptr(tail), 1024, a.fmt, osc, stream_ptr())
             assert rc in (0, 1), rc
             return rc
         return f
