@@ -252,7 +252,7 @@ def bench_dpt(args, dev: str, world: int, rank: int):
         flops = dpt._runner.flops_per_image(384) * B * args.steps
         ach = flops / elapsed / 1e12
         arith = dpt._runner.arith
-        peak = PEAK_BF16X3_TFLOPS if arith == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+        peak = {"bf16x3": PEAK_BF16X3_TFLOPS, "f16x2": PEAK_F16X2_TFLOPS}.get(arith, PEAK_F32_MFMA_TFLOPS)
         res = {"metric": "images/sec (DPT-Hybrid depth front-end forward, 384x384 -> 224x224 depth maps)",
                "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -262,7 +262,8 @@ def bench_dpt(args, dev: str, world: int, rank: int):
                           "batch_per_gpu": B, "parallelism": f"dp{world} (replicas, no collective: frozen)"},
                "roofline": {"bound": "mfma", "kernel": f"whole forward (convolutions / linear layers in {arith} arithmetic)",
                             "achieved": round(ach, 2), "peak": peak,
-                            "unit": "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)" if arith == "bf16x3" else "TFLOP/s",
+                            "unit": {"bf16x3": "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)",
+                                     "f16x2": "TFLOP/s (fp32-equivalent; peak = 2.5 PF fp16 / 3 products)"}.get(arith, "TFLOP/s"),
                             "frac": round(ach / peak, 4), "traffic": None,
                             "gflop_per_image": round(dpt._runner.flops_per_image(384) / 1e9, 1)}}
         if world == 1 and not args.no_cpu_baseline:

@@ -29,6 +29,7 @@ class DPT_Depthestimator(nn.Module):
         self.cfg = cfg or syn.DptConfig()
         self._weights: Dict[str, torch.Tensor] = syn.dpt_weights(seed, self.cfg)
         self._runner: Optional[DptRunner] = None
+        self.arith = "f16x2"     # DptRunner arithmetic: "f16x2" (default; raises if a layer input leaves the fp16 range), "bf16x3", "fp32"
 
     # ---- parameter plumbing (frozen: plain tensors, reference key names) --------------------------
     def _apply(self, fn, *args, **kwargs):               # .to(device) / .cuda() move the weight dict too
@@ -72,7 +73,7 @@ class DPT_Depthestimator(nn.Module):
     def forward(self, imgs: torch.Tensor) -> torch.Tensor:
         """[B,3,384,384] normalised with mean 0.5 / std 0.5 -> depth maps [B,384,384]   (DPT_model.py:63-67)."""
         if self._runner is None:
-            self._runner = DptRunner(self._weights, self.cfg)
+            self._runner = DptRunner(self._weights, self.cfg, arith=self.arith)
         return self._runner.forward(imgs)
 
     @torch.no_grad()

@@ -1733,6 +1733,30 @@ int dic_conv2d_bf16x3(const uint16_t* const x_planes[3], int B, int H, int W, in
   return conv_fwd_bf3(x_planes, d, w_planes, y_nhwc, nullptr, nullptr, tail_ws, (hipStream_t)stream, bias, nullptr, nullptr, act);
 }
 
+/* the same two on the f16x2 operand format (planes from dic_split_f16x2_paired; out_scale = 1 / (scale of x * scale of W)) */
+int dic_linear_f16x2(int M, int N, int K, const uint16_t* const x_planes[2], const uint16_t* const w_planes[2], const float* bias,
+                     int act, int accumulate, float* C, long long ldc, float out_scale, void* stream) {
+  DIC_REQUIRE(x_planes && w_planes && C && M > 0 && N > 0 && K > 0 && K % 32 == 0 && out_scale > 0.f, "linear_f16x2: bad arguments (K %% 32)");
+  Bf3Params p{};
+  p.M = M; p.N = N; p.K = K;
+  for (int i = 0; i < 2; ++i) { p.A.p[i] = x_planes[i]; p.B.p[i] = w_planes[i]; }
+  p.A.ld = K; p.A.kind = OPK_ROWK; p.B.ld = K; p.B.kind = OPK_ROWK;
+  p.A.paired = p.B.paired = 1;
+  p.ep = ep_store(C, ldc, bias, act);
+  p.ep.accumulate = accumulate;
+  p.fmt = 1; p.ep.alpha = out_scale;
+  return launch_bf3(p, (hipStream_t)stream, nullptr);
+}
+int dic_conv2d_f16x2(const uint16_t* const x_planes[2], int B, int H, int W, int Cin, const uint16_t* const w_planes[2],
+                     const float* bias, int CO, int KH, int KW, int stride, int pad, int act, float* y_nhwc, float* tail_ws,
+                     float out_scale, void* stream) {
+  DIC_REQUIRE(x_planes && w_planes && y_nhwc && Cin % 32 == 0 && out_scale > 0.f, "conv2d_f16x2: bad arguments (C %% 32)");
+  ConvDesc d{B, H, W, Cin, CO, KH, KW, stride, pad, 0};
+  const unsigned short* xp[3] = {x_planes[0], x_planes[1], nullptr};
+  const unsigned short* wp[3] = {w_planes[0], w_planes[1], nullptr};
+  return conv_fwd_bf3(xp, d, wp, y_nhwc, nullptr, nullptr, tail_ws, (hipStream_t)stream, bias, nullptr, nullptr, act, 256, 1, out_scale);
+}
+
 int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                     long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
                     float* C, long long ldc, const float* bias, void* stream) {

@@ -32,9 +32,11 @@ class DptRunner:
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: Optional[DptConfig] = None, arith: str = "bf16x3"):
         """arith: "bf16x3" (default) runs every convolution / linear layer whose contraction length is a multiple of 32 on the
         split-bf16 kernels (fp32-accurate: three bf16 planes per operand, six MFMA products); "fp32" keeps them
-        on the exact-fp32 MFMA kernels (the 3-channel stem and the pointwise head always are)."""
-        if arith not in ("bf16x3", "fp32"):
-            raise _lib.DicError("DptRunner: arith must be 'bf16x3' or 'fp32'")
+        on the exact-fp32 MFMA kernels (the 3-channel stem and the pointwise head always are); "f16x2" runs the same layers on the
+        two-plane fp16 operand format (three products, half the matrix-core work; weights scaled per layer so that their largest
+        magnitude lands in [2^14, 2^15), activations by 4: a layer input beyond +-16376 would overflow to inf)."""
+        if arith not in ("bf16x3", "f16x2", "fp32"):
+            raise _lib.DicError("DptRunner: arith must be 'bf16x3', 'f16x2' or 'fp32'")
         self.arith = arith
         self.lib = _lib.load()
         self.cfg = cfg or DptConfig()
@@ -70,24 +72,41 @@ class DptRunner:
             self.conv_w[key] = w
         self.pos_cache: Dict[tuple, torch.Tensor] = {}
         self.gn_ws: Optional[torch.Tensor] = None
-        self.w_planes: Dict[str, list] = {}                 # paired bf16x3 planes of [N][K] weight matrices (filters: OHWI rows)
+        self.w_planes: Dict[str, list] = {}                 # paired planes of [N][K] weight matrices (filters: OHWI rows)
+        self.w_scale: Dict[str, float] = {}                 # f16x2: the power of two each weight matrix was scaled by
         self.x_planes: Optional[list] = None                # scratch planes of the current layer's input
         self.tail_ws: Optional[torch.Tensor] = None
 
     # ---- split-bf16 operands ---------------------------------------------------------------------
-    def _split(self, x2d: torch.Tensor, out: Optional[list] = None) -> list:
+    ACT_SCALE = 4.0                                          # f16x2: activation planes hold 4 * x
+
+    def _split(self, x2d: torch.Tensor, out: Optional[list] = None, scale: float = ACT_SCALE) -> list:
         rows, k = x2d.shape
         n = (rows + 1) // 2 * 2 * k
         if out is None or out[0].numel() < n:
             out = [torch.empty(n, dtype=torch.int16, device=self.dev) for _ in range(3)]
+        if self.arith == "f16x2":
+            check(self.lib.dic_split_f16x2_paired(ptr(x2d), C.c_longlong(rows), k, C.c_float(scale), ptr(out[0]), ptr(out[1]), stream_ptr()),
+                  "dic_split_f16x2_paired")
+            return out
         check(self.lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(rows), k, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()),
               "dic_split_bf16x3_paired")
         return out
 
     def _weight_planes(self, key: str, w2d: torch.Tensor) -> list:
         if key not in self.w_planes:
-            self.w_planes[key] = self._split(w2d.contiguous())
+            scale = 1.0
+            if self.arith == "f16x2":                        # (once per layer: the weights are frozen)
+                wmax = float(w2d.abs().max())
+                if not (wmax > 0.0 and math.isfinite(wmax)):
+                    raise _lib.DicError(f"DptRunner: {key}: f16x2 needs finite, non-zero weights")
+                scale = 2.0 ** math.floor(14 - math.log2(wmax))
+            self.w_scale[key] = scale
+            self.w_planes[key] = self._split(w2d.contiguous(), scale=scale)
         return self.w_planes[key]
+
+    def _out_scale(self, key: str):
+        return C.c_float(1.0 / (self.ACT_SCALE * self.w_scale[key]))
 
     def _input_planes(self, x2d: torch.Tensor) -> list:
         self.x_planes = self._split(x2d, self.x_planes)      # one scratch set, grown to the largest layer input
@@ -110,11 +129,15 @@ class DptRunner:
         oh, ow = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         y = self._new(B, oh, ow, co)
         b = self.w[key + ".bias"] if bias else None
-        if self.arith == "bf16x3" and not nchw and ci % 32 == 0 and kh * kw <= 32:
+        if self.arith != "fp32" and not nchw and ci % 32 == 0 and kh * kw <= 32:
             if self.tail_ws is None:
                 self.tail_ws = torch.empty(256 * 64 * 64, dtype=torch.float32, device=self.dev)
             xp = self._input_planes(x.reshape(-1, ci))
             wp = self._weight_planes(key, w.reshape(co, -1))
+            if self.arith == "f16x2":
+                check(self.lib.dic_conv2d_f16x2(self._p3(xp), B, H, W, ci, self._p3(wp), ptr(b), co, kh, kw, stride, pad, ACT_NONE, ptr(y),
+                                                ptr(self.tail_ws), self._out_scale(key), stream_ptr()), "dic_conv2d_f16x2")
+                return y
             check(self.lib.dic_conv2d_bf16x3(self._p3(xp), B, H, W, ci, self._p3(wp), ptr(b), co, kh, kw, stride, pad, ACT_NONE, ptr(y),
                                              ptr(self.tail_ws), stream_ptr()), "dic_conv2d_bf16x3")
             return y
@@ -165,9 +188,14 @@ class DptRunner:
         m = x.numel() // k
         if out is None:
             out = self._new(*x.shape[:-1], n)
-        if self.arith == "bf16x3" and k % 32 == 0:
+        if self.arith != "fp32" and k % 32 == 0:
             xp = self._input_planes(x.reshape(m, k))
             wp = self._weight_planes(key, w.reshape(n, k))
+            if self.arith == "f16x2":
+                check(self.lib.dic_linear_f16x2(m, n, k, self._p3(xp), self._p3(wp), ptr(self.w[key + ".bias"]), act,
+                                                1 if accumulate else 0, ptr(out), C.c_longlong(n), self._out_scale(key), stream_ptr()),
+                      "dic_linear_f16x2")
+                return out
             check(self.lib.dic_linear_bf16x3(m, n, k, self._p3(xp), self._p3(wp), ptr(self.w[key + ".bias"]), act,
                                              1 if accumulate else 0, ptr(out), C.c_longlong(n), stream_ptr()), "dic_linear_bf16x3")
             return out
@@ -244,7 +272,7 @@ class DptRunner:
         # both products of the attention on the matrix cores (split-bf16 arithmetic, fp32 online softmax) when the runner
         # computes in bf16x3; the exact-fp32 runner keeps the plain fp32 vector kernel (workspace = NULL)
         ws = None
-        if self.arith == "bf16x3":
+        if self.arith != "fp32":
             self.lib.dic_vit_attention_workspace_bytes.restype = C.c_size_t
             need = self.lib.dic_vit_attention_workspace_bytes(B, N, self.cfg.heads)
             if getattr(self, "_attn_ws", None) is None or self._attn_ws.numel() < need:
@@ -318,6 +346,11 @@ class DptRunner:
         check(self.lib.dic_pointwise_dot(ptr(y), C.c_longlong(B * H * W), y.shape[-1], ptr(self.w["scratch.output_conv.4.weight"]),
                                          ptr(self.w["scratch.output_conv.4.bias"]), 1, ptr(out), stream_ptr()),
               "dic_pointwise_dot")
+        if self.arith == "f16x2" and not bool(torch.isfinite(out).all()):
+            # (the reference's post-processing maps NaN to 0.5: an overflow must not pass silently.  The estimator runs in epoch 0
+            #  only, one host synchronisation per batch is not on any hot path.)
+            raise _lib.DicError("DptRunner: non-finite depth map in f16x2 arithmetic - a layer input exceeded the fp16 range "
+                                "(+-16376 after the activation scale); use arith='bf16x3' for these weights")
         return out
 
     def flops_per_image(self, size: int = 384) -> float:

@@ -301,6 +301,13 @@ int dic_linear_bf16x3(int M, int N, int K, const uint16_t* const x_planes[3], co
 int dic_conv2d_bf16x3(const uint16_t* const x_planes[3], int B, int H, int W, int C, const uint16_t* const w_planes[3],
                       const float* bias, int CO, int KH, int KW, int stride, int pad, int act, float* y_nhwc, float* tail_ws,
                       void* stream);
+/* ... and on the f16x2 operand format (two planes per operand, dic_split_f16x2_paired; out_scale = 1 / (scale of x * scale of W)):
+ * half the matrix-core work, 2^-22 relative representation error per operand */
+int dic_linear_f16x2(int M, int N, int K, const uint16_t* const x_planes[2], const uint16_t* const w_planes[2], const float* bias,
+                     int act, int accumulate, float* C, long long ldc, float out_scale, void* stream);
+int dic_conv2d_f16x2(const uint16_t* const x_planes[2], int B, int H, int W, int Cin, const uint16_t* const w_planes[2],
+                     const float* bias, int CO, int KH, int KW, int stride, int pad, int act, float* y_nhwc, float* tail_ws,
+                     float out_scale, void* stream);
 int dic_gemm_bf16x3(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                     long long lda, const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, long long ldb,
                     float* C, long long ldc, const float* bias, void* stream);

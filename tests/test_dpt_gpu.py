@@ -119,10 +119,12 @@ def test_dpt_split_bf16_arithmetic_equals_exact_fp32(lib):
     wd = {k: v.to(DEV) for k, v in w.items()}
     x = syn.dpt_images(4, seed=6, size=160)
     ref = orc.dpt_forward(w, x, cfg)
-    out = {a: DptRunner(wd, cfg, arith=a).forward(x.to(DEV)) for a in ("bf16x3", "fp32")}
+    out = {a: DptRunner(wd, cfg, arith=a).forward(x.to(DEV)) for a in ("bf16x3", "f16x2", "fp32")}
     for a, got in out.items():
+        print(f"{a}: max err / scale vs oracle {_err(got, ref):.2e}")
         assert _err(got, ref) <= 2e-4, a
     assert _err(out["bf16x3"], out["fp32"].cpu()) <= 1e-4
+    assert _err(out["f16x2"], out["fp32"].cpu()) <= 1e-4      # (two fp16 planes, three products: dic_linear_f16x2, dic_conv2d_f16x2)
 
 
 def test_dpt_hybrid_full_model_384_vs_oracle(lib):
