@@ -13,8 +13,9 @@ gradient all-reduce (N>1) -> AdamW.  Nothing is skipped inside the timed region.
 batch i+1 runs on a side HIP stream concurrently with the rest of step i (it takes no gradient and is not touched
 by the optimiser, so this is pure software pipelining: K timed steps still contain K ResNet forwards - the ones launched
 in the last two timed steps belong to batches after the timed region, exactly as many as the warm-up's last steps
-contributed to the first timed steps - and the closing synchronize waits for every stream; since round 2 the forwards of
-the next TWO batches are in flight on two side streams (--prefetch-depth 1 = one; --no-overlap disables it).  Weak scaling: every rank
+contributed to the first timed steps - and the closing synchronize waits for every stream; the forwards of the next THREE
+batches are in flight on three side streams (--prefetch-depth; 2 until the f16x2 convolutions shortened the forward: 5970 ->
+6290 img/s with the third; --no-overlap disables it).  Weak scaling: every rank
 processes --batch images per step (default 64 = BASELINE.json configs[1]); value = N*batch*K / max-rank time.
 
 The JSON line also carries
@@ -337,7 +338,7 @@ def main():
                     help="separate workload (never mixed into the headline): forward of the frozen DPT-Hybrid depth "
                          "front-end of BASELINE config 5 at 384x384 + standardise + resize to 224 (depth_train.py:185-190)")
     ap.add_argument("--dpt-batch", type=int, default=8)
-    ap.add_argument("--prefetch-depth", type=int, default=2, choices=range(1, 13),
+    ap.add_argument("--prefetch-depth", type=int, default=3, choices=range(1, 13),
                     help="frozen-ResNet forwards of upcoming batches in flight on side streams (1 = round-1 behaviour)")
     ap.add_argument("--persist-grid", type=int, default=0,
                     help="workgroups per persistent convolution launch (dic_conv_persistent_grid; 0 = library default)")

@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       // before the consumers read slot g+1 (after this barrier) it must have landed; slot g+2 may stay in flight
       if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPL) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
+      if (!(ABL == 6 && (g & 1))) __builtin_amdgcn_s_barrier();    // ... and the consumers are done with stage st  (ABL 6, timing only: every other barrier skipped)
       if (ABL != 1 && g + NST < total) prefetch(smem + st * STAGE);
       st = st == NST - 1 ? 0 : st + 1;
     }
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this stage is in registers
       DIC_PIPE_PIN(1)
-      __builtin_amdgcn_s_barrier();
+      if (!(ABL == 6 && (g & 1))) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (NPL == 3) { DIC_PIPE_MFMA(1, 2, 0) } else { DIC_PIPE_MFMA(1, 1, 0) }
       if (g + 1 < total) { DIC_PIPE_READ_A(0, sbn, 0) DIC_PIPE_READ_A(0, sbn, 1) DIC_PIPE_READ_B(0, sbn, 0) DIC_PIPE_READ_B(0, sbn, 1) }
@@ -1212,7 +1212,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
   if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
   if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
-  if (code >= 50 && code <= 55) { g_bf3_ablate = code - 50; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
+  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
   if (code == 77) { g_bf3_ws = 0; return 0; }
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }
   if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
@@ -1376,6 +1376,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     else if (!halo && g_bf3_ws && g_bf3_ablate == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 1>), dim3(grid), dim3(512), 0, st, p);
     else if (!halo && g_bf3_ws && g_bf3_ablate == 4 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 3>), dim3(grid), dim3(512), 0, st, p);
     else if (!halo && g_bf3_ws && g_bf3_ablate == 5 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 4>), dim3(grid), dim3(512), 0, st, p);
+    else if (!halo && g_bf3_ws && g_bf3_ablate == 6 && !im && p.fmt == 1) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 6, 3, 1>), dim3(grid), dim3(512), 0, st, p);      // (56: f16x2, every other barrier skipped - timing only)
+    else if (!halo && g_bf3_ws && g_bf3_ablate == 0 && !im && p.fmt == 1) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
     else if (!halo && g_bf3_ws) { if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
                                   else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p); }
     else if (halo && g_bf3_ablate == 1) hipLaunchKernelGGL(conv3x3_bf3_halo_kernel<1>, dim3(grid), dim3(512), 0, st, p);

@@ -232,7 +232,7 @@ class CaptionTrainer:
         # the rest of the current step runs (prefetch_features).  Up to `prefetch_depth` forwards are in flight, each on its own
         # stream with its own workspace (_PrefetchSlot): two concurrent forwards fill each other's dependent-launch gaps and
         # shallow-grid idle CUs - 25.5 ms for two batch-64 forwards against 29.6 ms back to back (scripts/bench_resnet_concurrent.py).
-        self.prefetch_depth = int(os.environ.get("DIC_PREFETCH_DEPTH", "2"))
+        self.prefetch_depth = int(os.environ.get("DIC_PREFETCH_DEPTH", "3"))
         self.slots: List[_PrefetchSlot] = []
         self.slot_next = 0
         self.queue: List[tuple] = []   # FIFO of (imgs tensor, slot, done-event) in launch (= batch) order
@@ -366,7 +366,7 @@ class CaptionTrainer:
                    apply_update: bool = True, virtual_world: Optional[int] = None) -> torch.Tensor:
         """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync).
         next_imgs: images of the following batch, or the list [batch i+1, batch i+2, ...] of the next batches in order; their
-          (frozen) ResNet forwards run ahead on side streams, up to `prefetch_depth` (2) at a time.
+          (frozen) ResNet forwards run ahead on side streams, up to `prefetch_depth` (3) at a time.
         global_tokens: packed tokens (sum of lengths-1) of the GLOBAL batch when data parallel with variable-length
           captions; default = this rank's count x world size (exact for equal-length batches such as bench.py's).
         apply_update=False leaves the (scaled, all-reduced) gradients in self.flat.grad and skips AdamW;

@@ -201,6 +201,7 @@ def test_two_forwards_in_flight_equal_sequential_forwards(lib):
     batches = [syn.rgb_images(B, seed=180 + i, size=size).to(DEV) for i in range(6)]
     tr = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode="bf16x3")
     ref = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode="bf16x3")
+    tr.prefetch_depth = 2                                      # (the engine's default is 3 since round 3)
     tr.prefetch_features(batches[0])
     for i, x in enumerate(batches):
         if i + 1 < len(batches):
@@ -384,7 +385,7 @@ def test_full_pipeline_step_runs_and_learns(lib):
     assert np.isfinite(ev)
 
 
-@pytest.mark.parametrize("conv_mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("conv_mode", ["fp32", "bf16x3", "f16x2"])
 def test_prefetch_graph_replay_equals_eager(lib, conv_mode):
     """engine.prefetch_features replays the frozen ResNet forward from a captured hipGraph: the features of every
     batch and the BatchNorm running statistics (updated once per batch, in batch order - quirk Q1) must be bit-identical
@@ -394,6 +395,7 @@ def test_prefetch_graph_replay_equals_eager(lib, conv_mode):
 
     def run(use_graph):
         tr = CaptionTrainer(40, device=DEV, resnet_layers=TINY, conv_mode=conv_mode)
+        tr.prefetch_depth = 2
         tr.use_graph = use_graph
         feats = []
         tr.prefetch_features(batches[0])                       # two forwards in flight from here on, on two slots
