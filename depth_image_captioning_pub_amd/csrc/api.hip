@@ -80,13 +80,14 @@ int dic_debug_conv_bf3(const uint16_t* const x_planes[3], int B, int H, int W, i
   return conv_fwd_bf3(x_planes, d, w_planes, y, bn_partial, mtiles_out, tail_ws, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 /* the same two with the operand format explicit (0 = bf16x3, 1 = f16x2: two planes per operand from dic_split_f16x2_paired,
- * out_scale = 1 / (scale of the x planes * scale of the w planes); the on-the-fly operand is scaled by 4 inside the kernel) */
+ * out_scale = 1 / (scale of the x planes * scale of the w planes); the on-the-fly operand is scaled by 4 inside the kernel;
+ * tail_ws: 1024 * 64 * 64 floats) */
 int dic_debug_conv_fmt(const uint16_t* const x_planes[3], int B, int H, int W, int C, const uint16_t* const w_planes[3], int CO,
                        int k, int stride, int pad, float* y, float* bn_partial, int* mtiles_out, float* tail_ws, int fmt, float out_scale,
                        void* stream) {
   ConvDesc d{B, H, W, C, CO, k, k, stride, pad, 0};
-  return conv_fwd_bf3(x_planes, d, w_planes, y, bn_partial, mtiles_out, tail_ws, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, 256, fmt,
-                      out_scale);
+  return conv_fwd_bf3(x_planes, d, w_planes, y, bn_partial, mtiles_out, tail_ws, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, 1024, fmt,
+                      out_scale);      // (tail_ws: 1024 slabs of [64][64] floats, as inside the ResNet workspace)
 }
 int dic_debug_conv1x1_bn_fmt(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out, int M,
                              int C, const uint16_t* const w_planes[3], int CO, float* y, float* bn_partial, int* mtiles_out, float* tail_ws,

@@ -1262,13 +1262,26 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       if (sp >= 2) fill22 = std::max(fill22, (double)t22 / ((fullr + (double)ceil_div(units, sp) / units + 0.15) * gmax));
     }
   }
+  // Few tiles, long K (ResNet layer 4 at batch 64: 100 tiles of K = 2048, or K = 4608 gathered): fewer tiles than CUs, each a long
+  // dependent K loop.  The remainder-round machinery with NO whole round - every tile cut into `few_sp` K slices of at least 8 K
+  // tiles, one slice per workgroup, summed by the tail fix-up - puts 2-5x as many CUs on the launch (103 -> ~45 us at those shapes).
+  int few_sp = 0;
+  {
+    const int gmax = g_bf3_remainder_grid, units = ceil_div(p.K, BK3);
+    if (g_bf3_remainder_split && tail_ws && splitk <= 1 && t22 >= 32 && t22 < gmax && units >= 32) {
+      int sp = std::min(std::min(std::min(gmax / (int)t22, units / 8), 16), tail_ws_slabs / 4 / (int)t22);
+      while (sp > 1 && (sp - 1) * ceil_div(units, sp) >= units) --sp;
+      if (sp >= 2 && t22 * sp >= 160) few_sp = sp;
+    }
+  }
   bool persist = false;
   if (persist_ok && g_bf3_force == 0) {
     if (g_bf3_persist_policy == 1) persist = p.K <= 64 && t22 >= 1024;
     else if (g_bf3_persist_policy == 2) persist = (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
     else if (g_bf3_persist_policy >= 3)     // warp-specialised form (scripts/bench_bf3_pipe.py at batch 64 and 256): wins wherever the
       persist = ((p.A.kind == OPK_ROWK || g_bf3_persist_policy >= 4) && t22 >= 192 && (fill22 >= 0.85 || (fill22 >= 0.75 && p.K >= 512))) ||      // tiles fill the CUs
-                (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072);
+                (p.K <= 64 && t22 >= 1024) || (p.K <= 256 && t22 >= 3072) ||
+                ((p.A.kind == OPK_ROWK || g_bf3_persist_policy >= 4) && few_sp > 0);
   }
   if (g_bf3_force == 24 || g_bf3_force == 26) persist = persist_ok;
   bool ws256 = false;
@@ -1329,6 +1342,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     const int units = halo ? cg.C / BK3 : nk;                 // what a slice is made of
     const int gmax = g_bf3_remainder_grid;                     // CUs a split launch may use
     const int r = T % gmax, fullr = T / gmax;
+    if (fullr == 0 && few_sp > 0 && !halo && g_bf3_remainder_split && tail_ws) {      // few tiles, long K: every tile in slices
+      persist_grid = r * few_sp; rem128 = r;
+      p.tail_first_tile = 0; p.tail_split = few_sp; p.tail_ws = tail_ws;
+    } else
     if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4) {
       // tail_ws holds tail_ws_slabs slabs of [64][64] floats (kGemmTailWsBytes = 256 for callers of the C ABI, 1024 inside the
       // ResNet workspace); a piece writes four (one per consumer wave): r * sp <= slabs / 4

@@ -55,12 +55,23 @@ def test_depth_encoder_train_fwd_bwd(lib, B, size, seed):
     for k in st:
         _close(k, st_dev[k], st_ref[k], 1e-4)
     grads = native.depth_encoder_backward(tape, d_out.to(DEV))
-    for k in w:
-        # conv biases feed train-mode BN: true gradient 0, only rounding noise on both sides
-        if k.startswith("conv") and k.endswith("bias"):
-            _close("grad." + k, grads[k], wg[k].grad, 0.0, atol=5e-5)
-        else:
-            _close("grad." + k, grads[k], wg[k].grad, 2e-3)
+    try:
+        for k in w:
+            # conv biases feed train-mode BN: true gradient 0, only rounding noise on both sides
+            if k.startswith("conv") and k.endswith("bias"):
+                _close("grad." + k, grads[k], wg[k].grad, 0.0, atol=5e-5)
+            else:
+                _close("grad." + k, grads[k], wg[k].grad, 2e-3)
+    except AssertionError as direct:
+        # A direct comparison of gradients with the fp32 oracle holds only while both sides take the same ReLU / max-pool
+        # selections; a selection that is a tie at fp32 rounding level may fall either way (B = 1 at 520x520 did once the
+        # convolution's summation order changed: one flipped tie moved grad.conv2.weight by 1 % of its scale).  The stricter
+        # statement then has to hold: with the HIP path's selections replayed, everything agrees with fp64 to 2e-4 and every
+        # differing selection is a tie (the check the *_decision_replay tests run on all seeds).
+        if size == 224:
+            raise
+        print("direct gradient comparison failed (", str(direct).split(chr(10))[0], ") - checking with replayed selections")
+        _replay_check(w, st, depth, d_out)
     if size == 224:
         gold = load_golden("depth_encoder_train")
         check_packed(gold, "out49", y.reshape(B, 14, 14, 2048)[:, ::2, ::2].reshape(B, 49, 2048), 1e-3, 1e-4)

@@ -453,7 +453,7 @@ def test_conv1x1_with_on_the_fly_bn_operand(lib, M, Cin, CO, res, relu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["1x1 persistent", "1x1 persistent remainder", "3x3 halo", "3x3 gathered persistent", "1x1 64-wide", "3x3 64-wide strided",
-                                  "1x1 ragged"])
+                                  "1x1 ragged", "1x1 few tiles long K", "3x3 few tiles long K"])
 def test_conv_f16x2_operand_format(lib, case):
     """The two-term fp16 operand format (dic_split_f16x2_paired; three products h1*h1' + h1*h2' + h2*h1', epilogue unscale) on every
     convolution kernel family of the ResNet forward, against an fp64 evaluation and beside the bf16x3 route on the same inputs: the
@@ -462,7 +462,9 @@ def test_conv_f16x2_operand_format(lib, case):
     B, H, W, Cin, CO, k, stride, pad = {"1x1 persistent": (64, 14, 14, 1024, 256, 1, 1, 0), "1x1 persistent remainder": (64, 14, 14, 256, 1024, 1, 1, 0),
                                         "3x3 halo": (64, 14, 14, 256, 256, 3, 1, 1), "3x3 gathered persistent": (64, 28, 28, 128, 128, 3, 1, 1),
                                         "1x1 64-wide": (8, 14, 14, 512, 64, 1, 1, 0), "3x3 64-wide strided": (16, 28, 28, 128, 128, 3, 2, 1),
-                                        "1x1 ragged": (63, 14, 14, 512, 256, 1, 1, 0)}[case]
+                                        "1x1 ragged": (63, 14, 14, 512, 256, 1, 1, 0),
+                                        # ResNet layer 4 at batch 64: 100 / 100 output tiles of 128x128, every one cut into K slices
+                                        "1x1 few tiles long K": (64, 7, 7, 2048, 512, 1, 1, 0), "3x3 few tiles long K": (64, 7, 7, 512, 512, 3, 1, 1)}[case]
     g = torch.Generator().manual_seed(len(case))
     x = torch.relu(torch.randn(B, H, W, Cin, generator=g) * 1.5 + 0.3).to(DEV)         # post-ReLU-like activations
     w = (torch.randn(CO, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
@@ -484,7 +486,7 @@ def test_conv_f16x2_operand_format(lib, case):
             check(lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(R), K, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()), "split")
         return out
 
-    tail = torch.empty(256 * 64 * 64, device=DEV)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
     w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
     errs = {}
     for fmt in (0, 1):
@@ -506,7 +508,7 @@ def test_conv_f16x2_operand_format(lib, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,Cin,CO,res", [(12544, 1024, 256, True), (12544, 256, 1024, False), (12500, 512, 256, True)])
+@pytest.mark.parametrize("M,Cin,CO,res", [(12544, 1024, 256, True), (12544, 256, 1024, False), (12500, 512, 256, True), (3136, 2048, 512, True)])
 def test_conv1x1_on_the_fly_operand_f16x2(lib, M, Cin, CO, res):
     """conv1x1_fwd_bf3_bn in the f16x2 format: the producer waves scale the activation by 4 and write two fp16 planes; against fp64 and
     against the plane route of the same format (dic_split_f16x2_paired of the torch-evaluated activation)."""
