@@ -870,6 +870,178 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
 #undef DIC_PIPE_MFMA
 }
 
+// 256x128 form of the warp-specialised persistent kernel, for grids deep enough to fill the CUs with half as many tiles: eight
+// computing waves (4 x 2, 64x64 each) + four producer waves = three waves per SIMD, 168 registers each.  History: with the
+// pointer-form DMA and bf16x3 operands it lost 4-7 % against the 128x128 form (203 -> 216 us on 50176x256x1024) and was parked;
+// with the buffer-load DMA (no vector instructions in the producer's K loop) and the f16x2 format (half the matrix work per K
+// tile, so the second computing wave of a SIMD has latency to hide) it wins 15-19 % on the 1x1 expansions (layer-3 conv3
+// 34.4 -> 28.0 us, layer-2 conv3 41.1 -> 34.1) and is the f16x2 kernel for plain-epilogue row-major launches of >= 192 such tiles.
+// Operand bytes per MFMA drop by a quarter (72 KB per K tile for twice the MFMAs), which is what the 128x128 form still waits
+// for (scripts/bench_bf3_ws_ablate.py: 3100-3900 cycles per K tile against 2400-2600 without any DMA).  Two ring stages of
+// 72 KB; B fragments are single-buffered (the second computing wave of the SIMD covers their latency), A fragments stay
+// double-buffered by k-step.  BatchNorm partials per 64-row wave tile: [4*mtiles][2][N].  Bit-identical to gemm_bf3_kernel.
+template <int AK, int FMT = 0>
+__global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Params p) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int NPL = Bf3Fmt<FMT>::NPL;
+  constexpr int NST = NPL == 2 ? 3 : 2;                            // ring stages: 3 x 48 KB (two planes per operand) or 2 x 72 KB
+  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = NPL * APLANE, BOPER = NPL * BPLANE, STAGE = AOPER + BOPER;
+  constexpr int NDMA = NPL * (BM / 64) + NPL * (BN / 64);         // 18 | 12 DMA instructions per producer wave and K tile
+  __shared__ __align__(1024) unsigned short smem[NST * STAGE];     // 144 KB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = (p.K + BK3 - 1) / BK3;
+  const int T = p.mtiles * p.ntiles, G = gridDim.x;
+  const int ntl = (T - (int)blockIdx.x + G - 1) / G;
+  const int total = ntl * nkt;
+
+  if (wave >= 8) {
+    // ---------------- producer waves (8..11 -> row groups 0..3 of the loaders)
+    typename Bf3LoaderFor<AK, BM, NPL>::type la;
+    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
+    int pj = 0, pkt = 0;
+    {
+      const int t = xcd_remap(blockIdx.x, T);
+      la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+      lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+    }
+    auto prefetch = [&](unsigned short* stage) {
+      la.issue(pkt * BK3, stage);
+      lbld.issue(pkt * BK3, stage + AOPER);
+      if (++pkt == nkt) {
+        pkt = 0; ++pj;
+        if (pj < ntl) {
+          const int t = xcd_remap(blockIdx.x + pj * G, T);
+          la.init(p.A, (t / p.ntiles) * BM, p.M, p.K);
+          lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K);
+        }
+      }
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0)
+      if (s0 < total) prefetch(smem + s0 * STAGE);
+    if (total >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
+    int st = 0;
+    for (int g = 0; g < total; ++g) {
+      // slot g+1 must have landed before the consumers read it (after this barrier); with three stages slot g+2 may stay in flight
+      if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
+      if (g + NST < total) prefetch(smem + st * STAGE);
+      st = st == NST - 1 ? 0 : st + 1;
+    }
+    return;
+  }
+
+  // ---------------- consumer waves
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  const unsigned offA = (unsigned)((wm * 64 + i31) * 64), offB = (unsigned)((wn * 64 + i31) * 64);
+  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+  u32x4 fa[2][2][3], fb[2][3];                     // A: [k-step buffer][tile][plane];  B: [tile][plane]
+#define DIC_W_READ_A(KS_, SB_)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
+      bf3_lds_read(fa[KS_][i][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)(i * 32 * 64) + pos[KS_]);
+#define DIC_W_READ_B(KS_, SB_)                                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
+      bf3_lds_read(fb[j][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)(j * 32 * 64) + pos[KS_]);
+#define DIC_W_PIN(KS_)                                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                 \
+    asm volatile("" : "+v"(fa[KS_][i][pl])); asm volatile("" : "+v"(fb[i][pl])); }
+#define DIC_W_MFMA(KS_, PA_, PB_)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = bf3_mfma<FMT>(fa[KS_][i][PA_], fb[j][PB_], acc[i][j]);
+#define DIC_W_MFMA_ALL(KS_)                                                                                          \
+  if constexpr (NPL == 3) { DIC_W_MFMA(KS_, 2, 0) DIC_W_MFMA(KS_, 0, 2) DIC_W_MFMA(KS_, 1, 1) }                     \
+  DIC_W_MFMA(KS_, 1, 0) DIC_W_MFMA(KS_, 0, 1) DIC_W_MFMA(KS_, 0, 0)
+  __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
+  DIC_W_READ_A(0, sbase0)
+  int g = 0, st = 0;
+  for (int j = 0; j < ntl; ++j) {
+    for (int kt = 0; kt < nkt; ++kt, ++g) {
+      const int stn = st == NST - 1 ? 0 : st + 1;
+      const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
+      st = stn;
+      // k-step 0: its A fragments were requested one k-step ago; request its B fragments and k-step 1's A fragments
+      DIC_W_READ_B(0, sb) DIC_W_READ_A(1, sb)
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NPL) : "memory");
+      DIC_W_PIN(0)
+      __builtin_amdgcn_sched_barrier(0);
+      DIC_W_MFMA_ALL(0)
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 1: B fragments (same registers: the MFMAs above have been issued), then every read of this stage is done
+      DIC_W_READ_B(1, sb)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DIC_W_PIN(1)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NPL == 3) { DIC_W_MFMA(1, 2, 0) } else { DIC_W_MFMA(1, 1, 0) }
+      if (g + 1 < total) { DIC_W_READ_A(0, sbn) }
+      if constexpr (NPL == 3) { DIC_W_MFMA(1, 0, 2) DIC_W_MFMA(1, 1, 1) DIC_W_MFMA(1, 1, 0) }
+      DIC_W_MFMA(1, 0, 1) DIC_W_MFMA(1, 0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- seam: store the tile
+    const int t = xcd_remap(blockIdx.x + j * G, T);
+    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+    const bool full = (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 64 + 4 * h;
+    float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
+    if constexpr (FMT == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= p.ep.alpha;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (m0 + i * 32 + (r & 3) + 8 * (r >> 2) < p.M && n0 + jj * 32 < p.N)
+              col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {       // rows beyond M hold exact zeros (zero-filled operand rows)
+          cs[jj] += acc[i][jj][r]; cs2[jj] += acc[i][jj][r] * acc[i][jj][r];
+          acc[i][jj][r] = 0.f;
+        }
+      }
+    if (p.ep.stats) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cs2[jj] + __shfl_xor(cs2[jj], 32, 64);
+        const int n = n0 + jj * 32;
+        if (lane < 32 && n < p.N && tm * BM + wm * 64 < p.M) {      // (wave tiles entirely past M have no row in the table)
+          p.ep.stats[((long long)(tm * 4 + wm) * 2 + 0) * p.N + n] = a;
+          p.ep.stats[((long long)(tm * 4 + wm) * 2 + 1) * p.N + n] = b;
+        }
+      }
+    }
+  }
+#undef DIC_W_READ_A
+#undef DIC_W_READ_B
+#undef DIC_W_PIN
+#undef DIC_W_MFMA
+#undef DIC_W_MFMA_ALL
+}
+
 // 3x3 / stride-1 / pad-1 convolution on 14x14 maps (ResNet layer 3: 36 of the 50 3x3 convolutions) with the input tile's HALO
 // staged in LDS instead of an im2col gather.  Why: the contraction kernels of this file are bound by operand intake per CU
 // (see gemm_bf3_persist_kernel), and the gather is the worst customer - every tap re-fetches the same pixels as 64-B halves
@@ -1169,13 +1341,13 @@ static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only 
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
 static int g_bf3_remainder_grid = 256; // ... and the workgroups such a launch may use
+static int g_bf3_ws256 = 1;            // codes 80 / 81: 256x128 form of the warp-specialised kernel for f16x2 row-major plain-epilogue launches by policy (default) / never
 #ifdef DIC_EXPERIMENTS
 static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
-static int g_bf3_ws256 = 0;            // codes 80 / 81: 256x128 form of the warp-specialised kernel by policy on / off (measured 4-7 % SLOWER; 26 forces it)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_ablate = 0;           // 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 #else
-constexpr int g_bf3_stages = 2, g_bf3_ws256 = 0, g_bf3_ws = 1, g_bf3_ablate = 0;
+constexpr int g_bf3_stages = 2, g_bf3_ws = 1, g_bf3_ablate = 0;
 #endif
 template <int AK, int TM, int TN>
 static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
@@ -1207,6 +1379,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
 #endif
   if (code == 20 || code == 11 || code == 21 || code == 24) { g_bf3_force = code == 20 ? 0 : code; return 0; }
   if (code == 90 || code == 91) { g_bf3_remainder_split = code - 90; return 0; }      // remainder-round K split of the persistent kernels off / on (default)
+  if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
 #ifdef DIC_EXPERIMENTS
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
@@ -1214,7 +1387,6 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
   if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
   if (code == 77) { g_bf3_ws = 0; return 0; }
-  if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }
   if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
 #endif
   return -1;
@@ -1285,15 +1457,18 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   }
   if (g_bf3_force == 24 || g_bf3_force == 26) persist = persist_ok;
   bool ws256 = false;
-#ifdef DIC_EXPERIMENTS
-  {   // 256x128 form: half as many tiles must still fill the CUs
+  {   // 256x128 form (two computing waves per SIMD): half as many tiles must still fill the CUs.  f16x2 row-major launches with the
+      // plain epilogue (the ResNet's 1x1 expansions and downsample convolutions): measured 15-19 % faster there, slower below ~190 tiles
     const long long t42 = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128);
     const int rounds42 = (int)((t42 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
     const double fill42 = (double)t42 / ((double)rounds42 * g_bf3_persist_grid);
-    ws256 = g_bf3_force == 26 && persist_ok && plain_ep;
-    if (g_bf3_force == 0 && g_bf3_ws256 != 0 && persist && g_bf3_ws && plain_ep && t42 >= 512 && fill42 >= 0.75 && fill42 >= fill22 - 0.03 && p.K >= 128) ws256 = true;
-  }
+    if (g_bf3_force == 0 && g_bf3_ws256 != 0 && p.fmt == 1 && !p.a_raw && p.A.kind == OPK_ROWK && persist && few_sp == 0 && g_bf3_ws && plain_ep &&
+        t42 >= 192 && fill42 >= 0.75 && p.K >= 64)
+      ws256 = true;
+#ifdef DIC_EXPERIMENTS
+    if (g_bf3_force == 26) ws256 = persist_ok && plain_ep;
 #endif
+  }
   // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
   const ConvGeom& cg = p.A.g;
   const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && plain_ep && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
@@ -1379,14 +1554,20 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL>), dim3(grid), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK>), dim3(grid), dim3(512), 0, st, p);
   }
-#ifdef DIC_EXPERIMENTS
   else if (persist && ws256 && !halo) {
     p.mtiles = ceil_div(p.M, 256); p.ntiles = ceil_div(p.N, 128);
     g_last_mtiles = ceil_div(p.M, 64);     // statistics rows per 64-row wave tile
     const int T4 = p.mtiles * p.ntiles, grid = ceil_div(T4, ceil_div(T4, g_bf3_persist_grid));
-    if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_IM2COL>), dim3(grid), dim3(768), 0, st, p);
+    if (p.fmt == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1>), dim3(grid), dim3(768), 0, st, p);
+#ifdef DIC_EXPERIMENTS
+    else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_IM2COL>), dim3(grid), dim3(768), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK>), dim3(grid), dim3(768), 0, st, p);
-  } else if (persist) {                    // ablations of the product kernels, and the persistent kernel without producer waves
+#else
+    else DIC_REQUIRE(false, "gemm_bf3: no 256x128 kernel for this operand kind / format in the product library");
+#endif
+  }
+#ifdef DIC_EXPERIMENTS
+  else if (persist) {                    // ablations of the product kernels, and the persistent kernel without producer waves
     g_last_mtiles = 2 * p.mtiles;
     const int grid = ceil_div(T, ceil_div(T, g_bf3_persist_grid));
     if (!halo && g_bf3_ws && g_bf3_ablate == 2 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 2>), dim3(grid), dim3(512), 0, st, p);

@@ -376,6 +376,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   70 73 79     persistent kernel by policy: never / 1x1 convolutions by CU fill / + gathered convolutions (default)
  *   74 75 78     3x3 convolutions of 14x14 maps on the LDS-halo kernel: always / never / from 128 output tiles (default)
  *   76           accepted, no effect (the persistent kernel's only form here is the warp-specialised one)
+ *   80 81        f16x2 1x1 convolutions with the plain epilogue on the 256x128 twelve-wave kernel from 192 such tiles (default) / never
  *   90 91        remainder-round K split of the persistent kernels: off / on (default)
  *   100..104     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
  *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both / by operand

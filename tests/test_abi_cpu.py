@@ -36,7 +36,7 @@ def test_unknown_debug_switch_is_rejected():
     for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 121):
         assert lib.dic_debug_force_staged_gemm(code) != 0, code
         assert b"unknown" in lib.dic_last_error()
-    for code in (11, 21, 24, 70, 75, 74, 90, 100, 101, 102, 103, 20, 78, 76, 73, 79, 91, 104):  # (ending on the defaults)
+    for code in (11, 21, 24, 70, 75, 74, 90, 81, 100, 101, 102, 103, 20, 78, 76, 73, 79, 91, 104, 80):  # (ending on the defaults)
         assert lib.dic_debug_force_staged_gemm(code) == 0, code
 
 
@@ -54,5 +54,8 @@ def test_product_library_holds_no_parked_or_probe_code():
     """The parked kernels and the defect reproducer are built into libdic_experiments.so only (build.py --experiments)."""
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
-    for needle in ("probe", "pipe_kernel", "persist_kernel", "ws256", "decoder_fwd_persistent", "dic_debug_decoder_stamps"):
+    for needle in ("probe", "pipe_kernel", "persist_kernel", "decoder_fwd_persistent", "dic_debug_decoder_stamps"):
         assert needle not in out, needle
+    # the 256x128 twelve-wave kernel left the parked set in round 3 - in one instantiation: row-major operands, f16x2 format
+    ws256 = sorted({w for w in out.split() if "ws256" in w})
+    assert ws256 == ["_ZN3dic29gemm_bf3_persist_ws256_kernelILi0ELi1EEEvNS_9Bf3ParamsE"], ws256

@@ -453,7 +453,7 @@ def test_conv1x1_with_on_the_fly_bn_operand(lib, M, Cin, CO, res, relu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["1x1 persistent", "1x1 persistent remainder", "3x3 halo", "3x3 gathered persistent", "1x1 64-wide", "3x3 64-wide strided",
-                                  "1x1 ragged", "1x1 few tiles long K", "3x3 few tiles long K"])
+                                  "1x1 ragged", "1x1 few tiles long K", "3x3 few tiles long K", "1x1 256x128 tiles ragged", "1x1 256x128 tiles short K"])
 def test_conv_f16x2_operand_format(lib, case):
     """The two-term fp16 operand format (dic_split_f16x2_paired; three products h1*h1' + h1*h2' + h2*h1', epilogue unscale) on every
     convolution kernel family of the ResNet forward, against an fp64 evaluation and beside the bf16x3 route on the same inputs: the
@@ -464,7 +464,9 @@ def test_conv_f16x2_operand_format(lib, case):
                                         "1x1 64-wide": (8, 14, 14, 512, 64, 1, 1, 0), "3x3 64-wide strided": (16, 28, 28, 128, 128, 3, 2, 1),
                                         "1x1 ragged": (63, 14, 14, 512, 256, 1, 1, 0),
                                         # ResNet layer 4 at batch 64: 100 / 100 output tiles of 128x128, every one cut into K slices
-                                        "1x1 few tiles long K": (64, 7, 7, 2048, 512, 1, 1, 0), "3x3 few tiles long K": (64, 7, 7, 512, 512, 3, 1, 1)}[case]
+                                        "1x1 few tiles long K": (64, 7, 7, 2048, 512, 1, 1, 0), "3x3 few tiles long K": (64, 7, 7, 512, 512, 3, 1, 1),
+                                        # f16x2: >= 192 tiles of 256x128 -> the twelve-wave kernel (a ragged last tile; K = 64: two K tiles per tile)
+                                        "1x1 256x128 tiles ragged": (63, 14, 14, 256, 1024, 1, 1, 0), "1x1 256x128 tiles short K": (16, 56, 56, 64, 256, 1, 1, 0)}[case]
     g = torch.Generator().manual_seed(len(case))
     x = torch.relu(torch.randn(B, H, W, Cin, generator=g) * 1.5 + 0.3).to(DEV)         # post-ReLU-like activations
     w = (torch.randn(CO, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(DEV)
