@@ -452,10 +452,10 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 template <int AK, int ABL = 0, int NST = 3, int FMT = 0>      // FMT: operand format (top of the file); ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
 __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128;
-  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = 3 * APLANE, BOPER = 3 * BPLANE, STAGE = AOPER + BOPER;
+  constexpr int NPL = Bf3Fmt<FMT>::NPL;       // planes per operand
+  constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = NPL * APLANE, BOPER = NPL * BPLANE, STAGE = AOPER + BOPER;
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];
   constexpr bool kBn = AK == OPK_ROWK_BN;
-  constexpr int NPL = Bf3Fmt<FMT>::NPL;       // planes in use (the stage keeps three plane slots per operand)
   __shared__ float bn_tab[kBn ? 2 * kBnTabMax : 1];      // scale | shift of the on-the-fly operand (144 + 16 KB = all of the LDS)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -646,20 +646,14 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     for (int s0 = 0; s0 < DA; ++s0)
       if (s0 < total) load_a(sets[s0]);
     const bool steady_ok = total >= 2 * DA + 2;                    // shorter streams: plain vmcnt(0) waits
-    // (s_waitcnt takes an immediate: the few counts that occur are spelled out; a smaller count than necessary is always safe)
-    // the counted wait (one of a few immediates, picked by scalar branches), then ONE statement that names the registers of the
-    // slot just released: every use of them is ordered behind it.  (A wait with the registers as operands in each branch arm
-    // made the compiler copy the whole set - before the wait, i.e. before the data had arrived.)
+    // The wait names no registers (s_waitcnt takes an immediate, picked by scalar branches); ONE statement after it names the
+    // registers of the slot just released: every use of them is ordered behind it.  (A wait with the registers as operands in each
+    // branch arm made the compiler copy the whole set - before the wait, i.e. before the data had arrived.)
 #define DIC_PIN_SLOT(S_)                                                                                                          \
   asm volatile("" : "+v"((S_).ra[0]), "+v"((S_).ra[1]), "+v"((S_).ra[2]), "+v"((S_).ra[3]), "+v"((S_).rr[0]), "+v"((S_).rr[1]),   \
                "+v"((S_).rr[2]), "+v"((S_).rr[3]) :: "memory")
-    auto wait_early = [&]() {            // at most (DA - 1) * nl outstanding
-      if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 8) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 4) : "memory");
-    };
-    auto wait_steady = [&]() {           // at most (DA - 1) * (2 * NPL + nl) outstanding
-      if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (2 * NPL + 8)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * (2 * NPL + 4)) : "memory");
-    };
-    if (steady_ok) wait_early(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue (drains once per launch): slot 0 transformed, its register set reloaded
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DIC_PIN_SLOT(sets[0]);
     transform(sets[0], smem);
     if (DA < total) load_a(sets[0]);
@@ -672,15 +666,18 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
         const int g = g0 + u;
         if (g >= total) break;
         const int stn = st == NST - 1 ? 0 : st + 1;
+        // iteration g:  D(g+1) and L(g+1) done  ->  T(g+1)  ->  barrier g  ->  D(g+3) into the stage just freed, L(g+1+DA) into the
+        // register set just freed.  D(g+1) was issued in iteration g-2, L(g+1) long before it; younger than D(g+1) in issue order:
+        // L(g-1+DA), D(g+2), L(g+DA) [and stores of tiles that keep the fp32 copy - not counted: the wait then covers more, never
+        // less].  At the start and the end of the stream, where that pattern is incomplete, wait for everything.
+        // (Until this build the count was (DA-1) * (2*NPL + nl) - enough for L(g+1) but not for the weight tile D(g+1), which is
+        //  much younger; no test ever caught a late tile, the weights come from L2 within two K tiles, but nothing guaranteed it.)
         if (g + 1 < total) {
-          // L(g+1) done.  Younger in issue order: iterations g-DA+1 .. g-1 each issued D(j+3) (6) and L(j+1+DA) (nl) [and, in tiles that
-          // store, 4 stores - not counted: the wait then also covers stores that are DA-1 iterations old]; in the first DA-1
-          // iterations the prologue's loads take the place of the missing iterations; near the end of the stream, where slots
-          // are no longer issued, wait for everything.
-          // ((DA-1-g) * nl + g * (6 + nl) there; the prologue's count (DA-1) * nl is below all of them)
-          if (!(steady_ok && g + DA < total)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else if (g >= DA - 1) wait_steady();
-          else wait_early();
+          if (steady_ok && g >= 2 && g + DA < total) {
+            if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 8 + 2 * NPL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 4 + 2 * NPL) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
           DIC_PIN_SLOT(sets[(u + 1) % DA]);
           transform(sets[(u + 1) % DA], smem + stn * STAGE);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
