@@ -225,13 +225,15 @@ def test_resnet152_full_depth(lib, mode):
     _close("features", y, y_ref, 5e-3)
 
 
-def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(lib):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(lib, mode):
     """Batch-64 ResNet-152 forward (the size at which the launch policy puts the 1x1 convolutions on the persistent kernel), train-mode
     BatchNorm: with the BatchNorm-apply / residual / ReLU / split passes folded into the operand path of the consuming 1x1 convolutions
     (switch 103, the default; 101 / 102 = block inputs only / conv3 inputs only) the feature map and every running statistic must agree
     with the route that writes every convolution input as planes first (switch 100) bit for bit: the element-wise arithmetic (one
     fused multiply-add, one add, max, the round-to-nearest-even three-way split) and the order of the products are the same, only the
-    kernel that performs them differs."""
+    kernel that performs them differs.  Both operand formats (f16x2: the pass and the producer waves scale by 4 and split into two
+    fp16 planes with the same two roundings; an identity then always travels as fp32)."""
     w = syn.resnet152_weights(seed=125)
     imgs = syn.rgb_images(64, seed=123).to(DEV)
     results = {}
@@ -239,7 +241,7 @@ def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(
         for code in (100, 101, 102, 103, 103):
             assert lib.dic_debug_force_staged_gemm(code) == 0
             wd = _dev(w)
-            y = native.ResNetRunner(wd, conv_mode="bf16x3").forward(imgs, train_bn=True, compact=True)
+            y = native.ResNetRunner(wd, conv_mode=mode).forward(imgs, train_bn=True, compact=True)
             torch.cuda.synchronize()
             assert torch.isfinite(y).all()
             stats = torch.cat([wd[k].flatten() for k in sorted(wd) if "running" in k])

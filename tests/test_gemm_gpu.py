@@ -547,3 +547,39 @@ def test_conv1x1_on_the_fly_operand_f16x2(lib, M, Cin, CO, res):
     yd = y.double().cpu()
     stats = part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu()
     assert torch.allclose(stats[0], yd.sum(0), rtol=1e-5, atol=1e-4 * sc) and torch.allclose(stats[1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * sc)
+
+
+@pytest.mark.gpu
+def test_f16x2_activation_beyond_fp16_range_fails_loudly(lib):
+    """The f16x2 format stores 4 * x in fp16: an activation beyond +-16376 cannot be represented.  The documented behaviour is a loud
+    one - the plane holds inf, every output that touches it is inf / NaN - never a silently clamped value; bf16x3 on the same input
+    is exact."""
+    M, Cin, CO = 12544, 256, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, Cin, generator=g).to(DEV)
+    x[7, 5] = 2.0e4
+    w = (torch.randn(CO, Cin, generator=g) / Cin ** 0.5).to(DEV)
+    w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    outs = {}
+    for fmt in (0, 1):
+        xp = [torch.zeros(M * Cin, dtype=torch.int16, device=DEV) for _ in range(3 - fmt)] + ([None] if fmt else [])
+        wp = [torch.zeros(CO * Cin, dtype=torch.int16, device=DEV) for _ in range(3 - fmt)] + ([None] if fmt else [])
+        if fmt:
+            check(lib.dic_split_f16x2_paired(ptr(x), C.c_longlong(M), Cin, C.c_float(4.0), ptr(xp[0]), ptr(xp[1]), stream_ptr()), "split x")
+            check(lib.dic_split_f16x2_paired(ptr(w), C.c_longlong(CO), Cin, C.c_float(w_scale), ptr(wp[0]), ptr(wp[1]), stream_ptr()), "split w")
+        else:
+            check(lib.dic_split_bf16x3_paired(ptr(x), C.c_longlong(M), Cin, ptr(xp[0]), ptr(xp[1]), ptr(xp[2]), stream_ptr()), "split x")
+            check(lib.dic_split_bf16x3_paired(ptr(w), C.c_longlong(CO), Cin, ptr(wp[0]), ptr(wp[1]), ptr(wp[2]), stream_ptr()), "split w")
+        y = torch.zeros(M, CO, device=DEV)
+        pl = lambda ps: (C.c_void_p * 3)(*[t.data_ptr() if t is not None else None for t in ps])            # noqa: E731
+        check(lib.dic_debug_conv_fmt(pl(xp), 1, 1, M, Cin, pl(wp), CO, 1, 1, 0, ptr(y), None, None, ptr(tail), fmt,
+                                     C.c_float(1.0 / (4.0 * w_scale)), stream_ptr()), "conv")
+        torch.cuda.synchronize()
+        outs[fmt] = y
+    assert torch.isfinite(outs[0]).all()
+    bad_rows = (~torch.isfinite(outs[1])).any(1).nonzero().flatten().tolist()
+    assert bad_rows == [7], bad_rows          # exactly the output row that consumed the out-of-range activation, nothing silent elsewhere
+    ok = torch.ones(M, dtype=torch.bool); ok[7] = False
+    ref = (x.double().cpu() @ w.double().cpu().t())
+    assert float((outs[1].double().cpu()[ok] - ref[ok]).abs().max()) < 4e-6 * float(ref[ok].abs().max())
