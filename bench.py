@@ -169,7 +169,7 @@ def cpu_baseline(sample_b: int, iters: int, hard: bool = False):
         if it == 0:       # initial weights: the step the GPU leg of the parity gate repeats
             first = {"loss": float(loss), "packed": packed.clone(), "imgs": imgs, "depth": depth, "caps": caps,
                      "lens": lens, "drop": drop, "batch": sample_b, "loss64": float(loss64), "hard_u": hard_kw.get("hard_u"),
-                     "undecidable": orc.rows_undecidable_by_oracle(packed, packed64)}
+                     "undecidable": orc.rows_undecidable_by_oracle(packed, packed64), "packed64": packed64.clone()}
         params = {**dec, **enc}
         orc.adamw_step(params, {**gd, **ge}, m, v2, step=it + 1)
         times.append(time.perf_counter() - t0)
@@ -208,6 +208,10 @@ def parity_gate(first, dev: str, conv_mode: str, compact: bool, hard: bool = Fal
             "rows_undecidable_by_oracle": n_undec,
             "argmax_mismatches_on_decidable_rows": outside,
             "max_abs_dlogit": dmax,
+            # where the GPU path (in the ResNet arithmetic named below) and the oracle's own fp32 evaluation sit relative to the
+            # oracle's fp64 evaluation of the same step: the yardstick for "fp32-level"
+            "max_abs_dlogit_gpu_vs_fp64": float((logits.double() - first["packed64"]).abs().max()),
+            "max_abs_dlogit_oracle_fp32_vs_fp64": float((ref.double() - first["packed64"]).abs().max()),
             "undecidable_rows_cap": cap,
             "ok": bool(diff <= 1e-4 and outside == 0 and n_undec <= cap),
             "resnet_conv_mode": conv_mode, "annotation_cells": 49 if (compact and not hard) else 196,
@@ -531,6 +535,9 @@ def main():
                                    f"V={VOCAB}, ResNet-152 (random init, batch-stat BN) + depth CNN + soft-attention LSTM",
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": SEQ_LEN, "vocab": VOCAB,
                        "parallelism": f"dp{world}", "resnet_conv_mode": args.conv_mode,
+                       "resnet_arithmetic": {"fp32": "exact-fp32 MFMA", "bf16x3": "fp32 operands split exactly into three bf16 planes, six bf16 MFMA products, fp32 accumulation",
+                                             "f16x2": "fp32 operands as two fp16 planes of a power-of-two multiple (2^-22 representation error), three fp16 MFMA "
+                                                      "products, fp32 accumulation; error against fp64 = that of an fp32 evaluation (parity.max_abs_dlogit_*_vs_fp64)"}[args.conv_mode],
                        "cross_step_resnet_overlap": not args.no_overlap,
                        "resnet_forwards_in_flight": 0 if args.no_overlap else args.prefetch_depth, "annotation_cells": cells},
             "loss": round(loss_val, 5), "stages_ms": stages,
