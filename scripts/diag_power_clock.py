@@ -31,19 +31,20 @@ def sampler():
 
 
 DEV = "cuda:0"
+CONV_MODE = os.environ.get("DIC_CONV_MODE", "f16x2")      # ResNet arithmetic of the run (f16x2 = bench default since round 3)
 mode = sys.argv[1] if len(sys.argv) > 1 else "step"
 if mode == "step":
-    tr = CaptionTrainer(10000, device=DEV, seed=123, conv_mode="bf16x3")
+    tr = CaptionTrainer(10000, device=DEV, seed=123, conv_mode=CONV_MODE)
     imgs = syn.rgb_images(64, seed=123).to(DEV); depth = syn.depth_maps(64, seed=123).to(DEV)
     caps, lens = syn.captions_fixed(64, 10000, 20, seed=123); caps = caps.to(DEV)
-    body = lambda: tr.train_step(imgs, depth, caps, lens, next_imgs=[imgs, imgs])
+    body = lambda: tr.train_step(imgs, depth, caps, lens, next_imgs=[imgs] * tr.prefetch_depth)
     iters = 150
 else:
     n, G = int(sys.argv[2]), int(sys.argv[3])
     _lib.check(_lib.load().dic_conv_persistent_grid(G))
     rn = {k: v.to(DEV) for k, v in syn.resnet152_weights(seed=125).items()}
     stat = lambda k: k.endswith("running_mean") or k.endswith("running_var")
-    runners = [native.ResNetRunner({k: (v.clone() if stat(k) else v) for k, v in rn.items()}, conv_mode="bf16x3") for _ in range(n)]
+    runners = [native.ResNetRunner({k: (v.clone() if stat(k) else v) for k, v in rn.items()}, conv_mode=CONV_MODE) for _ in range(n)]
     imgs = syn.rgb_images(64, seed=123).to(DEV)
     outs = [torch.empty((64, 49, 2048), device=DEV) for _ in range(n)]
     streams = [torch.cuda.Stream() for _ in range(n)]
