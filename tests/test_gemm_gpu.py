@@ -583,3 +583,32 @@ def test_f16x2_activation_beyond_fp16_range_fails_loudly(lib):
     ok = torch.ones(M, dtype=torch.bool); ok[7] = False
     ref = (x.double().cpu() @ w.double().cpu().t())
     assert float((outs[1].double().cpu()[ok] - ref[ok]).abs().max()) < 4e-6 * float(ref[ok].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K", [(64, 256), (37, 96)])
+def test_split_f16x2_planes_equal_the_numpy_statement(lib, rows, K):
+    """dic_split_f16x2_paired against tests/test_f16x2_cpu.py::split2_f16 (numpy, IEEE round-to-nearest-even), bit for bit, in the
+    row-pair interleaved layout (include/dic.h) - values from the top of the fp16 range down into the subnormal second plane; an odd
+    row count leaves a zero pad row."""
+    import numpy as np
+    from test_f16x2_cpu import split2_f16
+    rng = np.random.default_rng(rows)
+    x = (rng.standard_normal((rows, K)) * np.exp(rng.uniform(-18, 8.0, (rows, K)))).astype(np.float32)
+    x[np.abs(x) >= 16000] = 1.0
+    xt = torch.from_numpy(x).to(DEV)
+    n = (rows + 1) // 2 * 2 * K
+    h1 = torch.full((n,), 0x7fff, dtype=torch.int16, device=DEV)
+    h2 = torch.full((n,), 0x7fff, dtype=torch.int16, device=DEV)
+    check(lib.dic_split_f16x2_paired(ptr(xt), C.c_longlong(rows), K, C.c_float(4.0), ptr(h1), ptr(h2), stream_ptr()), "split")
+    torch.cuda.synchronize()
+    e1, e2 = split2_f16(x, 4.0)
+    pad = (rows + 1) // 2 * 2
+    want = []
+    for e in (e1, e2):
+        full = np.zeros((pad, K), np.float16)
+        full[:rows] = e
+        # element (r, k) lives at ((r/2)*(K/32) + k/32)*64 + (r%2)*32 + k%32
+        want.append(full.reshape(pad // 2, 2, K // 32, 32).transpose(0, 2, 1, 3).reshape(-1).view(np.int16))
+    assert np.array_equal(h1.cpu().numpy(), want[0]), "first plane"
+    assert np.array_equal(h2.cpu().numpy(), want[1]), "second plane"
