@@ -20,9 +20,17 @@ processes --batch images per step (default 64 = BASELINE.json configs[1]); value
 
 The JSON line also carries
   roofline     - the contraction kernel instantiation with the largest total time (per-launch HIP events on the
-                 launch stream, algorithmic FLOPs / measured time; peak = 2.5 PFLOP/s dense fp16 / bf16 MFMA divided by the
-                 matrix-core products per fp32-equivalent multiply-add: 3 for the f16x2 operand format (833.3 TFLOP/s), 6 for
-                 bf16x3 (416.7 TFLOP/s); 157.3 TFLOP/s for the exact-fp32 MFMA kernels),
+                 launch stream).  Its bound is chosen by arithmetic intensity: algorithmic FLOPs / algorithmic HBM bytes of its
+                 launches (operands read once, output written once) against the machine balance peak / 8 TB/s, where peak =
+                 2.5 PFLOP/s dense fp16 / bf16 MFMA divided by the matrix-core products per fp32-equivalent multiply-add: 3 for
+                 the f16x2 operand format (833.3 TFLOP/s -> 104 FLOP/B = 312 matrix-core FLOP/B), 6 for bf16x3 (416.7), 157.3
+                 TFLOP/s for the exact-fp32 MFMA kernels.  Below the balance the kernel is priced in GB/s against 8 TB/s ("hbm"),
+                 above it in TFLOP/s ("mfma"); both fractions are always in the object,
+  resnet_forward - the whole frozen-encoder forward (9.6 of the 9.9 ms step): algorithmic FLOPs, algorithmic bytes (per layer:
+                 input + weights read, fp32 output written, BatchNorm pass read + normalised activation written), achieved TB/s
+                 and TFLOP/s fp32-equivalent over the un-overlapped forward,
+  decoder_roofline / decoder_roofline_batch256 - the attention + LSTM stage (fwd + loss + BPTT + AdamW) against the HBM roofline
+                 at the timed batch and at batch 256, where north_star quotes its 60 % target,
   cpu_baseline - the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample,
   parity       - same-run parity gate: the first oracle step of the cpu_baseline leg (initial weights,
                  batch --cpu-batch, explicit dropout mask) against one GPU step on the same tensors: |loss difference|
@@ -69,9 +77,10 @@ def profile_step(trainer, args_step):
     keys = (C.c_int * n)()
     ms = (C.c_double * n)()
     fl = (C.c_double * n)()
+    by = (C.c_double * n)()
     cnt = (C.c_longlong * n)()
     nout = C.c_int(0)
-    _lib.check(lib.dic_profile_end(n, keys, ms, fl, cnt, C.byref(nout)), "dic_profile_end")
+    _lib.check(lib.dic_profile_end_bytes(n, keys, ms, fl, by, cnt, C.byref(nout)), "dic_profile_end_bytes")
     rows = []
     for i in range(nout.value):
         k = keys[i]
@@ -88,13 +97,13 @@ def profile_step(trainer, args_step):
                                7: (f"gemm_bf3_persist_ws256_kernel<{kind}>", f"gemm_bf3_persist_ws256_kernel<{a}"),
                                8: (f"gemm_bf3_persist_kernel<{kind}>", f"gemm_bf3_persist_kernel<{a}")}[tcode]
                 rows.append({"kernel": name + (" [f16x2]" if f16 else ""), "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i],
-                             "flops": fl[i], "peak": peak})
+                             "flops": fl[i], "bytes": by[i], "peak": peak})
                 continue
             tm, tn = 1 + tcode // 2, 1 + tcode % 2          # workgroup tile 64*tm x 64*tn
             tile = "" if (tm, tn) == (1, 1) else f",{64 * tm}x{64 * tn}"
             rows.append({"kernel": f"gemm_bf3_kernel<{kind}{tile}>" + (" [f16x2]" if f16 else ""),
                          "rocprof_name": f"gemm_bf3_kernel<{a}, {tm}, {tn}, 2, 0, {int(f16)}>",
-                         "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "peak": peak})
+                         "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "bytes": by[i], "peak": peak})
             continue
         dma = k >= 1000
         k %= 1000
@@ -104,9 +113,71 @@ def profile_step(trainer, args_step):
                 else f"gemm_kernel<{tile},{tile},{KIND_NAMES[a]},{KIND_NAMES[b]}>")
         rows.append({"kernel": name, "rocprof_name": (f"gemm_dma_kernel<{tile}, {tile}, {a}, 2>" if dma else
                                                        f"gemm_kernel<{tile}, {tile}, {a}, {b}, 0>"),
-                     "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i]})
+                     "launches": int(cnt[i]), "total_ms": ms[i], "flops": fl[i], "bytes": by[i]})
     rows.sort(key=lambda r: -r["total_ms"])
     return rows
+
+
+def kernel_roofline(row):
+    """Which roofline bounds a contraction instantiation, from its own launches: arithmetic intensity (algorithmic FLOPs / algorithmic
+    HBM bytes) against the machine balance of the arithmetic it runs in.  Returns the fields shared by `roofline` and
+    `all_contraction_kernels`."""
+    peak = row.get("peak", PEAK_F32_MFMA_TFLOPS)
+    t = row["total_ms"] * 1e-3
+    tf = row["flops"] / t / 1e12
+    gbs = row["bytes"] / t / 1e9
+    intensity = row["flops"] / max(row["bytes"], 1.0)
+    balance = peak * 1e12 / (PEAK_HBM_TBS * 1e12)              # FLOP (fp32-equivalent) per byte at which both roofs meet
+    bound = "hbm" if intensity < balance else "mfma"
+    return {"bound": bound, "intensity_flop_per_byte": round(intensity, 1), "machine_balance_flop_per_byte": round(balance, 1),
+            "tflops": round(tf, 2), "frac_of_mfma_peak": round(tf / peak, 4),
+            "gbytes_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / (PEAK_HBM_TBS * 1e3), 4),
+            "algorithmic_bytes_per_launch": round(row["bytes"] / max(row["launches"], 1)),
+            "gflop_per_launch": round(row["flops"] / max(row["launches"], 1) / 1e9, 3)}
+
+
+def resnet_forward_algorithmic(batch: int, size: int = 224):
+    """(FLOPs, HBM bytes) one ResNet-152 forward with batch-statistics BatchNorm has to spend, layer by layer.  A convolution reads
+    its input and its weights once and writes its raw fp32 output once (4 B per element whatever the operand format: two fp16
+    planes or fp32); its BatchNorm needs the complete output before it can normalise any of it (batch statistics, quirk Q1), so the
+    output is read once more, together with the identity at the end of a block, and the normalised activation written once - unless
+    the consumer is the next convolution itself, whose input read is already counted."""
+    from depth_image_captioning_pub_amd import synthetic as syn
+    flops = byts = 0.0
+    h = w = size
+    # (key, bn, co, ci, k, stride, pad) in execution order: stem; per block conv1, conv2, conv3, [downsample]
+    spec = syn.resnet152_spec()
+    hw_in = {}
+    idx = 0
+    key, bn, co, ci, k, st, pd = spec[idx]; idx += 1
+    oh = (h + 2 * pd - k) // st + 1
+    M = batch * oh * oh
+    flops += 2.0 * M * co * ci * k * k
+    byts += 4.0 * (batch * h * w * ci + co * ci * k * k + M * co) + 4.0 * M * co        # conv + BN read (pool output below)
+    h = (oh + 2 - 3) // 2 + 1
+    byts += 4.0 * batch * h * h * co                                                    # pooled activation written
+    cin = co
+    for s_i, (planes, nb) in enumerate(zip((64, 128, 256, 512), (3, 8, 36, 3))):
+        for b in range(nb):
+            stride = 2 if (s_i > 0 and b == 0) else 1
+            ho = h // stride
+            Min, Mout = batch * h * h, batch * ho * ho
+            # conv1 1x1, conv2 3x3 (stride), conv3 1x1, [downsample 1x1 (stride)]
+            for (c_out, c_in, kk, m_in, m_out) in ((planes, cin, 1, Min, Min), (planes, planes, 3, Min, Mout), (planes * 4, planes, 1, Mout, Mout)):
+                flops += 2.0 * m_out * c_out * c_in * kk * kk
+                byts += 4.0 * (m_in * c_in + c_out * c_in * kk * kk + m_out * c_out)    # input + weights read, raw output written
+                byts += 4.0 * m_out * c_out                                             # BatchNorm pass reads the raw output
+            byts += 4.0 * (Min * planes + Mout * planes)                                # conv1 / conv2 activations written for their consumers
+            if b == 0:
+                flops += 2.0 * Mout * planes * 4 * cin
+                byts += 4.0 * (Mout * cin + planes * 4 * cin + Mout * planes * 4) + 4.0 * Mout * planes * 4     # (a strided 1x1 reads every stride-th pixel)
+            else:
+                byts += 4.0 * Mout * planes * 4                                         # identity read
+            byts += 4.0 * Mout * planes * 4                                             # block output written
+            idx += 4 if b == 0 else 3
+            cin, h = planes * 4, ho
+    assert idx == len(spec)
+    return flops, byts
 
 
 def pmc_for(rocprof_name: str, batch: int = 64):
@@ -315,14 +386,15 @@ def launch_ranks(n: int) -> int:
     return child.wait()
 
 
-def main():
+def build_parser():
+    from depth_image_captioning_pub_amd.native import DEFAULT_CONV_MODE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", choices=["fp32", "bf16x3", "f16x2"], default="f16x2",
+    ap.add_argument("--conv-mode", choices=["fp32", "bf16x3", "f16x2"], default=DEFAULT_CONV_MODE,
                     help="ResNet convolutions: exact-fp32 MFMA; bf16x3 = exact three-way bf16 split, 6 matrix-core products; f16x2 "
                          "(default) = two fp16 planes of scaled values, 3 products (2^-22 representation error per operand: the "
                          "network's error against fp64 stays that of an fp32 evaluation - tests/test_gemm_gpu.py, "
@@ -346,9 +418,51 @@ def main():
                     help="frozen-ResNet forwards of upcoming batches in flight on side streams (1 = round-1 behaviour)")
     ap.add_argument("--persist-grid", type=int, default=0,
                     help="workgroups per persistent convolution launch (dic_conv_persistent_grid; 0 = library default)")
-    ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-iters", type=int, default=4)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-batch", type=int, default=0,
+                    help="batch of the CPU-oracle leg = batch of the same-run parity gate; 0 (default) = the timed batch, capped at 64 "
+                         "(one fp32 oracle step at batch 64 takes ~4 s on 16 cores, the fp64 yardstick step ~25 s)")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-decoder-batch256", action="store_true",
+                    help="skip the extra decoder-stage measurement at batch 256 (decoder_roofline_batch256)")
+    return ap
+
+
+def decoder_stage_roofline(dev: str, batch: int, hard: bool, reference_cells: bool):
+    """The attention + LSTM stage alone (decoder forward + loss + BPTT + AdamW; depth encoder excluded) at `batch`, on synthetic
+    encoder features resident in HBM: mean of 5 steps after 2 warm-up steps, stage-boundary events on the main stream, nothing
+    else on the chip.  north_star quotes its 60 %-of-HBM target at batch 256; the timed workload is batch 64."""
+    from depth_image_captioning_pub_amd import native, synthetic as syn
+    from depth_image_captioning_pub_amd.engine import CaptionTrainer
+    tr = CaptionTrainer(VOCAB, device=dev, seed=123, hard=hard, resnet_layers=(1, 1, 1, 1))       # (the encoder is not run here)
+    cells = 196 if (hard or reference_cells) else 49
+    g = torch.Generator(device="cpu").manual_seed(7)
+    feats = torch.rand((batch, cells, 2048), generator=g).to(dev)
+    depth = syn.depth_maps(batch, seed=7).to(dev)
+    caps, lens = syn.captions_fixed(batch, VOCAB, SEQ_LEN, seed=7)
+    caps = caps.to(dev)
+    extra = {"gumbel_u": syn.gumbel_uniforms(SEQ_LEN, batch, seed=9).to(dev), "temp": 1.0} if hard else {}
+    acc = {}
+    for it in range(7):
+        tr.timing = it >= 2
+        tr.train_step(None, depth, caps, lens, precomputed_features=feats, **extra)
+        torch.cuda.synchronize()
+        if it >= 2:
+            for k, v in tr.stage_ms().items():
+                acc[k] = acc.get(k, 0.0) + v / 5
+    ms = sum(acc.get(k, 0.0) for k in ("decoder_fwd", "loss", "decoder_bwd", "adamw"))
+    byts = bytes_dec(batch, SEQ_LEN, VOCAB, cells)
+    bw = byts / (ms * 1e-3) / 1e12
+    return {"bound": "hbm", "stage": "decoder fwd + loss + BPTT bwd + AdamW", "batch": batch, "ms": round(ms, 3),
+            "stages_ms": {k: round(acc.get(k, 0.0), 3) for k in ("decoder_fwd", "loss", "decoder_bwd", "adamw")},
+            "annotation_cells": cells, "algorithmic_bytes": byts, "achieved": round(bw, 3), "peak": PEAK_HBM_TBS, "unit": "TB/s",
+            "frac": round(bw / PEAK_HBM_TBS, 4), "target_frac": 0.60,
+            "frac_if_priced_at_196_cells": round(bytes_dec(batch, SEQ_LEN, VOCAB, 196) / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
+
+
+def main():
+    args = build_parser().parse_args()
+    if args.cpu_batch <= 0:
+        args.cpu_batch = min(args.batch, 64)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))
@@ -436,6 +550,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    trainer.check_status()                  # f16x2 overflow guard: a tripped step would have skipped its update (DicError here)
+    dropped_timed = trainer.prefetch_dropped     # must be 0: a dropped prefetch means the timed steps ran un-overlapped forwards
 
     # ---- per-stage and per-kernel measurements: two extra steps after the timed region (every rank runs
     #      them so the collectives stay matched) ----
@@ -495,23 +611,54 @@ def main():
     parity_failed = False
     if rank == 0:
         top = prof[0]
-        ach = top["flops"] / (top["total_ms"] * 1e-3) / 1e12
+        kr = kernel_roofline(top)
+        ach = kr["tflops"]
         traffic, mfma_util = pmc_for(top["rocprof_name"], B)
         peak = top.get("peak", PEAK_F32_MFMA_TFLOPS)
-        roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s" if peak == PEAK_F32_MFMA_TFLOPS else
-                            "TFLOP/s (fp32-equivalent; peak = 2.5 PF fp16 / 3 products)" if peak == PEAK_F16X2_TFLOPS else
-                            "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)",
-                    "frac": round(ach / peak, 4), "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        tf_unit = ("TFLOP/s" if peak == PEAK_F32_MFMA_TFLOPS else
+                   "TFLOP/s (fp32-equivalent; peak = 2.5 PF fp16 / 3 products)" if peak == PEAK_F16X2_TFLOPS else
+                   "TFLOP/s (fp32-equivalent; peak = 2.5 PF bf16 / 6 products)")
+        hbm = kr["bound"] == "hbm"
+        roofline = {"bound": kr["bound"], "kernel": top["kernel"],
+                    "achieved": kr["gbytes_per_s"] if hbm else round(ach, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm else round(peak, 1),
+                    "unit": "GB/s (algorithmic bytes per launch / average launch time)" if hbm else tf_unit,
+                    "frac": kr["frac_of_hbm_peak"] if hbm else kr["frac_of_mfma_peak"],
+                    "bound_by": f"arithmetic intensity {kr['intensity_flop_per_byte']} FLOP/B (fp32-equivalent) against a machine balance of "
+                                f"{kr['machine_balance_flop_per_byte']} FLOP/B for this arithmetic ({round(peak, 1)} TFLOP/s / 8 TB/s)",
+                    "algorithmic_bytes_per_launch": kr["algorithmic_bytes_per_launch"], "gflop_per_launch": kr["gflop_per_launch"],
+                    "mfma_side": {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": tf_unit, "frac": kr["frac_of_mfma_peak"]},
+                    "hbm_side": {"achieved": kr["gbytes_per_s"], "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": kr["frac_of_hbm_peak"],
+                                 "frac_of_measured_copy_rate_6.3TBps": round(kr["gbytes_per_s"] / 6300.0, 4)},
+                    "frac_of_exact_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic,
+                    "traffic_over_algorithmic": round(traffic / kr["algorithmic_bytes_per_launch"], 3) if traffic else None,
                     "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc run (FETCH_SIZE x2 gfx950 "
                                     "wide-read correction + WRITE_SIZE, KB->bytes), " + pmc_for.source + " (scripts/pmc_summary.py)",
                     "mfma_util_pmc": mfma_util,
                     "launches_per_step": top["launches"],
                     "avg_launch_us": round(top["total_ms"] * 1e3 / top["launches"], 2),
                     "all_contraction_kernels": [
-                        {"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
-                         "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2)} for r in prof]}
+                        dict({"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3)},
+                             **{k: v for k, v in kernel_roofline(r).items()
+                                if k in ("bound", "tflops", "gbytes_per_s", "intensity_flop_per_byte", "frac_of_mfma_peak", "frac_of_hbm_peak")})
+                        for r in prof]}
+        # ---- the whole frozen-encoder forward against both roofs (the step IS this forward: VERDICT r03 item 3)
+        rn_ms = stages.get("resnet152_fwd", 0.0)
+        rn_flops, rn_bytes = resnet_forward_algorithmic(B)
+        rn_peak = {"f16x2": PEAK_F16X2_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}.get(args.conv_mode, PEAK_F32_MFMA_TFLOPS)
+        resnet_forward = None
+        if rn_ms > 0:
+            rn_tf, rn_tb = rn_flops / (rn_ms * 1e-3) / 1e12, rn_bytes / (rn_ms * 1e-3) / 1e12
+            resnet_forward = {
+                "ms": round(rn_ms, 3), "what": "ResNet-152 forward, batch-statistics BatchNorm, alone on the chip (the un-overlapped extra step)",
+                "algorithmic_gflop": round(rn_flops / 1e9, 1), "algorithmic_gbytes": round(rn_bytes / 1e9, 3),
+                "bytes_formula": "per convolution 4 B x (input + weights + raw output) + 4 B x output for the BatchNorm pass; per block "
+                                 "4 B x (conv1 + conv2 activations written, identity read, block output written): resnet_forward_algorithmic()",
+                "intensity_flop_per_byte": round(rn_flops / rn_bytes, 1), "machine_balance_flop_per_byte": round(rn_peak / PEAK_HBM_TBS, 1),
+                "bound": "hbm" if rn_flops / rn_bytes < rn_peak / PEAK_HBM_TBS else "mfma",
+                "achieved_tbytes_per_s": round(rn_tb, 3), "frac_of_hbm_peak": round(rn_tb / PEAK_HBM_TBS, 4),
+                "achieved_tflops_fp32_equivalent": round(rn_tf, 1), "frac_of_mfma_peak": round(rn_tf / rn_peak, 4),
+                "hbm_floor_ms": round(rn_bytes / (PEAK_HBM_TBS * 1e12) * 1e3, 3), "mfma_floor_ms": round(rn_flops / (rn_peak * 1e12) * 1e3, 3)}
         dec_ms = sum(stages.get(k, 0.0) for k in ("decoder_fwd", "loss", "decoder_bwd", "adamw"))
         # priced against the bytes the kernels actually have to move: the compact layout's 4x saving on the feature
         # passes is an algorithmic saving, reported separately and NOT counted as bandwidth
@@ -548,9 +695,13 @@ def main():
             "stages_under_load_note": "the same stage boundaries inside the pipelined step (mean of 5 extra steps with a host sync "
                                       "each): the main stream next to the ResNet forwards in flight on the side streams; "
                                       "'resnet152_fwd' there is only the wait for the prefetched features",
-            "roofline": roofline, "decoder_roofline": decoder_roofline,
+            "roofline": roofline, "resnet_forward": resnet_forward, "decoder_roofline": decoder_roofline,
             "other_conv_mode": alt,
+            "prefetch_dropped": dropped_timed,
         }
+        if world == 1 and not args.no_decoder_batch256 and B != 256:
+            torch.cuda.empty_cache()
+            result["decoder_roofline_batch256"] = decoder_stage_roofline(dev, 256, args.hard, args.reference_cells)
         result["config"]["ranks"] = world
         result["config"]["collective"] = (f"{backend} all-reduce of 2 gradient buckets over {world} ranks" if world > 1
                                           else "none (single rank)")
@@ -563,6 +714,10 @@ def main():
             result["parity"] = parity_gate(first, dev, args.conv_mode, not args.reference_cells, hard=args.hard)
         print(json.dumps(result), flush=True)
         parity_failed = bool(result.get("parity")) and not result["parity"]["ok"]
+        if dropped_timed:
+            print(f"bench.py: {dropped_timed} prefetched ResNet forward(s) were DISCARDED inside the warm-up / timed region - the steps "
+                  "did not run the pipelined schedule the number claims", file=sys.stderr)
+            parity_failed = True
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -5,8 +5,10 @@ CNNEncoder_Atten keeps the reference's parameter tree - `backbone` = Sequential 
 ResNet-152 children()[:-1] with avgpool -> AdaptiveAvgPool2d(14) - so its state_dict keys
 (`backbone.0.weight`, `backbone.4.0.conv1.weight`, `backbone.1.running_mean`, ...) match and a torchvision
 IMAGENET1K_V2 checkpoint loads with load_state_dict.  torchvision itself is not needed: the forward runs
-dic_resnet_fwd (exact-fp32 MFMA implicit-GEMM convolutions).  No pretrained weights are reachable
-offline, so construction uses torchvision's initialiser (Kaiming-normal fan-out, BN gamma=1 beta=0).
+dic_resnet_fwd in the arithmetic `conv_mode` names (default native.DEFAULT_CONV_MODE = "f16x2", the benchmarked
+mode: fp32 operands as two fp16 planes, fp32-level results, guarded against the format's range limit - see
+forward(); "bf16x3" / "fp32" = exact operands).  No pretrained weights are reachable offline, so construction
+uses torchvision's initialiser (Kaiming-normal fan-out, BN gamma=1 beta=0).
 """
 from __future__ import annotations
 
@@ -46,8 +48,11 @@ def _make_stage(inplanes: int, planes: int, blocks: int, stride: int) -> nn.Sequ
 
 
 class CNNEncoder_Atten(nn.Module):
-    def __init__(self, encoded_img_size: int, layers=_LAYERS):
+    def __init__(self, encoded_img_size: int, layers=_LAYERS, conv_mode: str = None):
         super().__init__()
+        self.conv_mode = conv_mode or native.DEFAULT_CONV_MODE      # (not part of the reference's signature: keyword only in practice)
+        self.check_overflow = True     # f16x2: read the guard word after every forward (one 4-byte device read = a host sync, as
+                                       # the reference's own loop does with loss.item() every iteration, depth_train.py:224)
         if encoded_img_size != 14:
             raise DicError("the native path is built for the reference's 14x14 annotation grid")
         self._layers = tuple(layers)
@@ -70,16 +75,23 @@ class CNNEncoder_Atten(nn.Module):
         sd = {"backbone." + k: v for k, v in self.backbone.state_dict(keep_vars=True).items()
               if not k.endswith("num_batches_tracked")}
         key = tuple((v.data_ptr(), v._version) for k, v in sd.items() if k.endswith("weight") and v.dim() == 4)
+        key = key + (self.conv_mode,)
         if self._runner is None or key != self._runner_key:
-            self._runner = native.ResNetRunner({k: v.detach() for k, v in sd.items()}, self._layers)
+            self._runner = native.ResNetRunner({k: v.detach() for k, v in sd.items()}, self._layers, conv_mode=self.conv_mode)
             self._runner_key = key
         return self._runner
 
     @torch.no_grad()
     def forward(self, imgs: torch.Tensor) -> torch.Tensor:
         """[B,3,H,W] -> [B,196,2048].  train() mode normalises with batch statistics and updates the running
-        statistics although the weights are frozen (quirk Q1, depth_train.py:161); eval() uses running stats."""
-        out = self._native().forward(imgs, train_bn=self.training)
+        statistics although the weights are frozen (quirk Q1, depth_train.py:161); eval() uses running stats.
+        In f16x2 arithmetic an activation beyond +-16376 does not fit the operand planes: the library then raises its guard
+        word and fills the features with NaN, and this method raises DicError (check_overflow = False leaves the check to the
+        caller: runner.check_overflow() or the NaN features)."""
+        runner = self._native()
+        out = runner.forward(imgs, train_bn=self.training)
+        if self.check_overflow:
+            runner.check_overflow()
         if self.training:
             for m in self.modules():
                 if isinstance(m, nn.BatchNorm2d):

@@ -16,7 +16,7 @@ from collections import deque
 import numpy as np
 import torch
 
-from ... import synthetic as syn
+from ... import native, synthetic as syn
 from ..._lib import DicError
 from ...engine import CaptionTrainer
 from ..config import ConfigTrain
@@ -93,7 +93,12 @@ def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None
     rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
     trainer = CaptionTrainer(config.vocab_size, device=config.device, seed=123 + int(ext), lr=config.lr, hard=hard,
                              dropout=config.dropout, lam=lam, process_group=process_group, use_depth=depth_branch,
-                             conv_mode=getattr(config, "conv_mode", "fp32"))
+                             conv_mode=getattr(config, "conv_mode", None))
+    if rank == 0:
+        print(f"[{tag}] frozen ResNet-152 convolutions in {trainer.conv_mode} arithmetic (config.conv_mode; bench.py --conv-mode "
+              f"default: {native.DEFAULT_CONV_MODE})", flush=True)
+    if stats is not None:
+        stats.update(conv_mode=trainer.conv_mode)
     dev = config.device
     temp = torch.tensor(1.0)
     val_loss_best = float("inf")
@@ -134,6 +139,7 @@ def _train(ext, useData, hard: bool, config=None, process_group=None, stats=None
             window.append(loss)
             if len(window) > config.moving_avg:
                 window.popleft()
+        trainer.check_status()          # f16x2 overflow guard: raises DicError if a step of this epoch tripped it (engine.py)
         train_loss = float(torch.stack(losses).mean().item())
         if rank == 0:
             with open(train_loss_file, "a") as f:

@@ -20,6 +20,8 @@ class ConfigTrain(object):
         self.lr_drop = [20]             # :25 (scheduler is built but never stepped: quirk Q2)
         self.temp_sch = 10              # :26 temperature re-annealed every 10 epochs (hard path)
         self.device = "cuda:0"          # :68
+        self.conv_mode = "f16x2"        # (not in the reference) arithmetic of the frozen ResNet-152: "f16x2" = the benchmarked mode
+                                        # (native.DEFAULT_CONV_MODE; overflow-guarded), "bf16x3" / "fp32" = exact operands
         self.moving_avg = 100           # :71
         self.save_directory_soft = self.cwd + "/exp_result/base_soft"           # config.py:45 (base-soft; base_train.py:253 also puts base-hard here)
         self.save_directory_hard = self.cwd + "/exp_result/base_hard"           # :51

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libdic_hip.so")
 LIB_EXPERIMENTS_PATH = os.path.join(HERE, "libdic_experiments.so")      # parked kernels + ablation switches: scripts/ only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "dic.h")
 
+ABI_VERSION = 200       # DIC_ABI_VERSION of the include/dic.h these bindings were written against (load() refuses any other library)
 _lib: Optional[C.CDLL] = None
 
 c_fp = C.c_void_p       # device pointers travel as void* (tensor.data_ptr())
@@ -36,8 +37,20 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.dic_version.restype = C.c_int
     lib.dic_last_error.restype = C.c_char_p
+    got = lib.dic_version()
+    if got != ABI_VERSION:      # argument lists / struct layouts differ between versions: calling on would pass garbage pointers
+        raise DicError(f"{path} has ABI version {got}, these bindings need {ABI_VERSION} (include/dic.h DIC_ABI_VERSION): rebuild it "
+                       "with `python -m depth_image_captioning_pub_amd.build --force`")
+    lib.dic_struct_bytes.restype = C.c_size_t
     _lib = lib
     return lib
+
+
+def check_struct(lib: C.CDLL, which: int, mirror) -> None:
+    """The ctypes mirror of a struct of include/dic.h must have the size the library compiled (dic_struct_bytes)."""
+    want = lib.dic_struct_bytes(which)
+    if want != C.sizeof(mirror):
+        raise DicError(f"ctypes mirror {mirror.__name__} is {C.sizeof(mirror)} bytes, the library's struct {want}: the binding is stale")
 
 
 def check(rc: int, what: str = "") -> None:

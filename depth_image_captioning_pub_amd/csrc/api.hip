@@ -12,7 +12,18 @@ namespace dic { void decoder_debug_persistent(int on); void decoder_persist_debu
 
 extern "C" {
 
-int dic_version(void) { return 100; }
+int dic_version(void) { return DIC_ABI_VERSION; }
+size_t dic_struct_bytes(int which) {
+  switch (which) {
+    case 0: return sizeof(dic_conv_bn_layer);
+    case 1: return sizeof(dic_decoder_weights);
+    case 2: return sizeof(dic_decoder_grads);
+    case 3: return sizeof(dic_depth_encoder_weights);
+    case 4: return sizeof(dic_depth_encoder_grads);
+    case 5: return sizeof(dic_depth_bn_state);
+    default: return 0;
+  }
+}
 const char* dic_last_error(void) { return last_error(); }
 
 int dic_gemm_f32(int M, int N, int K, const float* A, long long lda, int a_colk, const float* B, long long ldb,
@@ -111,6 +122,11 @@ int dic_profile_begin(void) { return gemm_profile_begin(); }
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
   DIC_REQUIRE(keys && total_ms && total_flops && launches && n_out && max_entries > 0, "profile_end: bad arguments");
   return gemm_profile_end(max_entries, keys, total_ms, total_flops, launches, n_out);
+}
+int dic_profile_end_bytes(int max_entries, int* keys, double* total_ms, double* total_flops, double* total_bytes, long long* launches,
+                          int* n_out) {
+  DIC_REQUIRE(keys && total_ms && total_flops && total_bytes && launches && n_out && max_entries > 0, "profile_end_bytes: bad arguments");
+  return gemm_profile_end(max_entries, keys, total_ms, total_flops, launches, n_out, total_bytes);
 }
 
 }  // extern "C"

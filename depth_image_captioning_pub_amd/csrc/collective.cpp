@@ -29,12 +29,14 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_once;
 char g_load_err[256] = "";
+char g_rccl_path[512] = "";     // file the entry points were resolved from (dladdr): makes a second RCCL in the process visible
+bool g_rccl_reused = false;     // true: the copy the process already held (RTLD_NOLOAD) - false: this library loaded one itself
 
 void load_rccl() {
   const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
   for (const char* n : names)                       // an RCCL this process already holds wins (torch's, if torch is loaded)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) { g_rccl_reused = true; break; }
   if (!h)
     for (const char* n : names)
       if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
@@ -51,7 +53,10 @@ void load_rccl() {
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     snprintf(g_load_err, sizeof(g_load_err), "librccl.so lacks the NCCL 2 entry points");
     g_rccl.handle = nullptr;
+    return;
   }
+  Dl_info info{};
+  if (dladdr((void*)g_rccl.AllReduce, &info) && info.dli_fname) snprintf(g_rccl_path, sizeof(g_rccl_path), "%s", info.dli_fname);
 }
 
 int rccl_ready() {
@@ -120,8 +125,20 @@ int dic_comm_ranks(const dic_comm* comm, int* nranks, int* rank) {
 int dic_comm_destroy(dic_comm* comm) {
   if (!comm) return DIC_OK;
   DIC_TRY(rccl_ready());
-  DIC_CHECK_RCCL(g_rccl.CommDestroy(comm->comm));
-  delete comm;
+  const int r = g_rccl.CommDestroy(comm->comm);
+  delete comm;                       // the handle is gone whatever RCCL answered (no leak on the error path)
+  if (r != kNcclSuccess) {
+    set_last_error("ncclCommDestroy -> RCCL error %d (%s)", r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return DIC_ERR_HIP;
+  }
+  return DIC_OK;
+}
+
+int dic_comm_info(char* buf, size_t bytes) {
+  DIC_REQUIRE(buf && bytes > 0, "dic_comm_info: null buffer");
+  DIC_TRY(rccl_ready());
+  snprintf(buf, bytes, "rccl=%s;%s", g_rccl_path[0] ? g_rccl_path : "?",
+           g_rccl_reused ? "reused (already loaded in this process)" : "loaded by libdic_hip.so (no RCCL was resident)");
   return DIC_OK;
 }
 

@@ -93,7 +93,16 @@ __device__ __forceinline__ void split3_bf16(float v, unsigned short& h, unsigned
 }
 
 constexpr float kF16ActScale = 4.0f;       // f16x2 ACTIVATION planes hold 4 * x: |x| up to 16376 (larger values become inf: a loud failure); weights carry a
-                                           // per-layer scale that puts their largest magnitude in [2^14, 2^15)
+                                           // per-layer scale that puts their largest magnitude in (2^13, 2^14]
+constexpr float kF16Max = 65504.0f;        // largest finite fp16: a plane value beyond it is inf and every product it enters inf - inf = NaN
+// Overflow guard of the f16x2 format.  Every kernel that WRITES f16x2 planes (bn_apply_planes, bn_relu_maxpool, the producer waves of the
+// on-the-fly-operand convolution, split_f16x2_paired) checks |s * v| <= 65504 for the values it splits and raises a caller-owned status
+// word otherwise (NaN counts as a violation).  The word is what keeps the failure loud: downstream ReLUs are fmaxf(v, 0), which turn the
+// NaN of an overflowed product into 0.  dic_resnet_fwd* fill their output with NaN when it is set; dic_adamw_step / dic_bn_ema_update
+// skip their update when given the word (include/dic.h).  Rare path: one atomic per offending thread.
+__device__ __forceinline__ void f16x2_raise(unsigned* status) { if (status) atomicOr(status, 1u); }
+__device__ __forceinline__ bool f16x2_out_of_range(float v, float s) { return !(fabsf(v) * s <= kF16Max); }
+
 // fp32 -> two fp16 planes of s*v (s a power of two chosen by the caller): h1 = rn(s*v), h2 = rn(s*v - h1); |s*v - h1 - h2| <= 2^-22 |s*v|
 // (h2 may be subnormal: the matrix cores honour it).  Values beyond the fp16 range become inf - the caller's scale must prevent that.
 __device__ __forceinline__ void split2_f16(float v, float s, unsigned short& h1, unsigned short& h2) {

@@ -35,7 +35,8 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse = nullptr,
-                       int* bn_fused = nullptr, int fmt = 0, float out_scale = 1.0f);
+                       int* bn_fused = nullptr, int fmt = 0, float out_scale = 1.0f,
+                       unsigned* status = nullptr /* f16x2: overflow guard word (common.h) */);
 bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs);
 constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a larger tail region: every CU can take a remainder piece
 // bn_fuse: when the launch is tail-split, finalize the train-mode BatchNorm inside the fix-up launch (*bn_fused = 1)
@@ -58,7 +59,8 @@ int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& 
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
                         unsigned short* lo, hipStream_t st);
-int split_f16x2_paired(const float* x, long long rows, int K, float scale, unsigned short* h1, unsigned short* h2, hipStream_t st);
+int split_f16x2_paired(const float* x, long long rows, int K, float scale, unsigned short* h1, unsigned short* h2, hipStream_t st,
+                       unsigned* status = nullptr /* overflow guard word (common.h) */);
 
 // Depth-encoder layer 1 (1 -> 128 channels, 7x7, stride 3, no padding) on packed fp32 vector FMAs (conv1_depth.hip).
 //   fwd: y [B,OH,OW,128] = conv(x [B,H,W]) + bias; bn_partial (nullable) receives one [2][128] row of sums per workgroup,

@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
 }
 
 __global__ void __launch_bounds__(256) bn_ema_update_kernel(float* __restrict__ running, const float* __restrict__ delta,
-                                                             long long n, float keep) {
+                                                             long long n, float keep, const unsigned* __restrict__ skip_if_raised) {
+  if (skip_if_raised && *skip_if_raised != 0u) return;       // f16x2 overflow guard (dic.h): a flagged forward's statistics are dropped
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) running[i] = keep * running[i] + delta[i];
 }
@@ -134,9 +135,14 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  * trainer applies the deltas on the main stream in the order the batches are consumed, which keeps the running statistics
  * in batch order (quirk Q1, depth_train.py:161) however many forwards are in flight. */
 int dic_bn_ema_update(float* running, const float* delta, long long n, float momentum, void* stream) {
+  return dic_bn_ema_update_guarded(running, delta, n, momentum, nullptr, stream);
+}
+int dic_bn_ema_update_guarded(float* running, const float* delta, long long n, float momentum, const uint32_t* skip_if_raised,
+                              void* stream) {
   DIC_REQUIRE(running && delta && n > 0 && momentum >= 0.f && momentum <= 1.f, "bn_ema_update: bad arguments");
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(bn_ema_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, running, delta, n, 1.0f - momentum);
+  hipLaunchKernelGGL(bn_ema_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, running, delta, n, 1.0f - momentum,
+                     (const unsigned*)skip_if_raised);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -167,6 +167,7 @@ static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
 }
 
 struct RnWs {
+  unsigned* status;                 // first word of the workspace: the f16x2 overflow guard (common.h; documented in include/dic.h)
   float* act[6];                    // raw conv outputs (conv1, conv2, conv3, downsample) + two fp32 block-input buffers (bf16x3 mode)
   unsigned short* planes[3][3];     // bf16x3 mode: three rotating activation buffers x (hi, mid, lo)
   unsigned short* stem_planes[3];   // bf16x3 mode: zero-padded NHWC4 image planes of the stem (conv_stem_bf3)
@@ -182,6 +183,7 @@ struct RnWs {
 static RnWs rn_carve(void* p, size_t bytes, const RnPlan& pl, int mode, bool* ov) {
   Carver c(p, bytes);
   RnWs w{};
+  w.status = c.take<unsigned>(64);       // (first: dic.h promises the word at offset 0 of the workspace)
   for (int i = 0; i < (mode >= 1 ? 6 : 4); ++i) w.act[i] = c.take<float>(pl.max_act);
   if (mode >= 1)
     for (int i = 0; i < 3; ++i)
@@ -233,14 +235,14 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
   const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
   int fused = 0;
   const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
-                      (double)d.M(), kBnEps, kBnMomentum};
+                      (double)d.M(), kBnEps, kBnMomentum, fmt ? ws.status : nullptr};
   DIC_TRY(conv_fwd_bf3(xp, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, st, nullptr,
                        (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, ACT_NONE, kResnetTailSlabs, fmt,
                        fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f));
   if (train_bn && fused) return DIC_OK;        // statistics were finalized inside the tail fix-up launch
   if (train_bn)
     return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn,
-                             ws.red, st);
+                             ws.red, st, fmt ? ws.status : nullptr);
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
@@ -253,14 +255,15 @@ static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* 
   int mtiles = 0, fused = 0;
   const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
   const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
-                      (double)d.M(), kBnEps, kBnMomentum};
+                      (double)d.M(), kBnEps, kBnMomentum, fmt ? ws.status : nullptr};
   const int rc = conv1x1_fwd_bf3_bn(raw, in_bn.scale, in_bn.shift, res, 1, act_out, d.M(), d.C, wp, d.CO, y, train_bn ? ws.partial : nullptr,
                                     &mtiles, ws.tail, kResnetTailSlabs, st, (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, fmt,
-                                    fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f);
+                                    fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f, fmt ? ws.status : nullptr);
   if (rc != DIC_OK) return rc;
   if (train_bn && fused) return DIC_OK;
   if (train_bn)
-    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, ws.red, st);
+    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, ws.red, st,
+                             fmt ? ws.status : nullptr);
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
@@ -281,6 +284,7 @@ void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand_switch = mask < 0 ? -1
 static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, const float* imgs_nchw, int B, int train_bn,
                           float* features, const RnPlan& pl, const RnWs& ws, hipStream_t st, int pool_out, int fmt) {
   const int g_fuse_bn_operand = g_fuse_bn_operand_switch >= 0 ? g_fuse_bn_operand_switch : (fmt ? 1 : 3);
+  unsigned* const guard = fmt ? ws.status : nullptr;      // f16x2 overflow guard word (zeroed by resnet_fwd_impl)
   size_t ci = 0;
   float *R2 = ws.act[0], *R3 = ws.act[1], *R1 = ws.act[2], *Cf = ws.act[3];
   float* const IN[2] = {ws.act[4], ws.act[5]};
@@ -304,13 +308,13 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       DIC_TRY(conv_stem_bf3(imgs_nchw, B, c.d.H, c.d.W, 64, ws.stem_planes, wp, R3, train_bn ? ws.partial : nullptr, &mtiles, st));
       if (train_bn)
         DIC_TRY(bn_finalize_train(ws.partial, mtiles, c.d.M(), 64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn,
-                                  ws.red, st));
+                                  ws.red, st, guard));
       else
         DIC_TRY(bn_finalize_eval(64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn, st));
     } else
     DIC_TRY(conv_bn(imgs_nchw, c.d, layers[c.layer], R3, ws.partial, ws.bn, ws.red, ws.tail, train_bn, st));
     // BN + ReLU + maxpool straight into the planes of the first bottleneck's input (no fp32 copy, no split pass)
-    DIC_TRY(bn_relu_maxpool(R3, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, nullptr, nullptr, st, Xp));
+    DIC_TRY(bn_relu_maxpool(R3, B, c.d.OH(), c.d.OW(), 64, &ws.bn, 1, 3, 2, 1, nullptr, nullptr, st, Xp, guard));
   }
   for (int s = 0; s < 4; ++s) {
     bool pending = false;                  // the block input is not materialised: it is relu(bn3(R3) + pend_res)
@@ -326,7 +330,7 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
         float* in_b = IN[b & 1];
         int rc = conv_bn_bf3_fused(R3, ws.bn3, pend_res, in_b, c1.d, layers[c1.layer], R1, ws, train_bn, st, ws.bn, fmt);
         if (rc == 1) {                      // shape not on the persistent kernel: form the input as planes (+ fp32) after all
-          DIC_BN_APPLY_PLANES_OUT(R3, pend_res, nullptr, in_b, Xp, c1.d.M(), c1.d.C, ws.bn3, 1, st);
+          DIC_BN_APPLY_PLANES_OUT(R3, pend_res, nullptr, in_b, Xp, c1.d.M(), c1.d.C, ws.bn3, 1, st, nullptr, guard);
           rc = conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st, nullptr, fmt);
         }
         DIC_TRY(rc);
@@ -334,7 +338,7 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       } else {
         DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st, nullptr, fmt));
       }
-      DIC_BN_APPLY_PLANES(R1, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st);
+      DIC_BN_APPLY_PLANES(R1, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st, nullptr, guard);
       DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], R2, ws, train_bn, st, &ws.bn2, fmt));
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
@@ -345,7 +349,7 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
         int rc = (g_fuse_bn_operand & 2) ? conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3, fmt)
                                          : 1;
         if (rc == 1) {
-          DIC_BN_APPLY_PLANES(R2, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn2, 1, st);
+          DIC_BN_APPLY_PLANES(R2, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn2, 1, st, nullptr, guard);
           rc = conv_bn_bf3(P2, c3.d, layers[c3.layer], R3, ws, train_bn, st, &ws.bn3, fmt);
         }
         DIC_TRY(rc);
@@ -373,12 +377,16 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       float* y32 = last ? (pool_out == 0 ? features : X) : nullptr;
       if (fmt && b + 1 < blocks[s]) { y32 = IN[(b + 1) & 1]; in32_carry = y32; }
       DIC_BN_APPLY_PLANES_OUT(R3, identity, identity ? nullptr : idp, y32, P1, c3.d.M(), c3.d.CO,
-                              ws.bn3, 1, st, b == 0 ? &ws.bn_ds : nullptr);
+                              ws.bn3, 1, st, b == 0 ? &ws.bn_ds : nullptr, guard);
       std::swap(Xp, P1);
     }
   }
-  if (pool_out == 0) return DIC_OK;       // features already hold the [B, outH*outW, 2048] map
-  return adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, pool_out, features, st);
+  if (pool_out != 0) DIC_TRY(adaptive_avgpool(X, B, pl.outH, pl.outW, 2048, nullptr, 0, pool_out, features, st));
+  // (pool_out == 0: features already hold the [B, outH*outW, 2048] map)
+  // the loud end of the overflow guard: downstream ReLUs turn the NaN of an overflowed product into 0, so the raised word - not the
+  // values - is what fills the output with NaN (dic.h); one tiny launch, nothing written when the word is clear
+  if (guard) DIC_TRY(poison_if_raised(features, (long long)B * (pool_out ? pool_out * pool_out : pl.outH * pl.outW) * 2048, guard, st));
+  return DIC_OK;
 }
 
 }  // namespace dic
@@ -619,6 +627,7 @@ static int resnet_fwd_impl(const dic_conv_bn_layer* layers, int n_layers, const 
   DIC_REQUIRE(mode >= 0 && mode <= 2, "resnet_fwd: mode must be 0 (exact-fp32 MFMA), 1 (bf16x3 split MFMA) or 2 (f16x2 split MFMA)");
   RnWs ws = rn_carve(workspace, workspace_bytes, pl, mode, &ov);
   DIC_REQUIRE(!ov, "resnet_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+  DIC_CHECK_HIP(hipMemsetAsync(ws.status, 0, 256, st));      // status word (first bytes of the workspace): clear at the start of every forward
   if (mode >= 1) {
     for (int i = 1; i < n_layers; ++i) {
       DIC_REQUIRE(layers[i].w_hi && layers[i].w_mid, "resnet_fwd: split-operand modes need split weights");

@@ -105,14 +105,16 @@ struct BnFuseArgs {
   float *scale, *shift, *mean, *invstd;   // outputs (BnBuf)
   double count;                           // rows of the activation (B*OH*OW)
   float eps, momentum;
+  unsigned* status = nullptr;             // f16x2 overflow guard word (common.h): raised on non-finite statistics
 };
 // requires p.ep.stats, tail tiles aligned to whole tile rows (tail_first_tile % ntiles == 0), no bias / activation.
 bool gemm_tail_fixup_bn_eligible(const GemmParams& p, int tail_tiles);
 int gemm_launch_tail_fixup_bn(const GemmParams& p, int tail_tiles, const BnFuseArgs& bn, hipStream_t st);
-void gemm_profile_mark_begin(hipStream_t st, double flops, int key);
+void gemm_profile_mark_begin(hipStream_t st, double flops, int key, double bytes = 0.0 /* algorithmic HBM bytes of the launch */);
 void gemm_profile_mark_end(hipStream_t st);
 int gemm_profile_begin();
-int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
+int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out,
+                     double* total_bytes = nullptr);
 GemmEpilogue ep_store(float* C, long long ldc, const float* bias = nullptr, int act = ACT_NONE);
 
 // convenience: C = A(MxK, rowk) * B(NxK, rowk)^T etc. with automatic split-K for skinny shapes

@@ -595,7 +595,9 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
     bn.shift[c] = bn.beta[c] - (float)mean * sc;
     bn.mean[c] = (float)mean;
     bn.invstd[c] = invstd;
-    if (bn.running_mean) {
+    const bool finite = fabs(a) <= 1.7e308 && fabs(b) <= 1.7e308;      // (as bn_finalize_train_kernel: the overflow guard's second line)
+    if (!finite) f16x2_raise(bn.status);
+    if (bn.running_mean && finite) {
       const double unb = bn.count > 1.0 ? var * bn.count / (bn.count - 1.0) : var;
       bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
       bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unb;
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
 // ------------------------------------------------------------------------------------------
 // Optional per-launch timing (bench.py roofline): HIP events recorded on the launch stream around
 // every contraction launch, summed per kernel instantiation (tile, A kind, B kind).
-struct ProfRec { hipEvent_t e0, e1; double flops; int key; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int key; double bytes; };
 static bool g_prof_on = false;
 static bool g_force_v1 = false;   // benchmarking switch: register-staged kernel for every shape
 static int g_dma_stages = 2;
@@ -750,10 +752,10 @@ static hipEvent_t prof_event() {
 
 // hooks for contraction launches that do not go through gemm_launch (gemm_bf3.hip)
 static ProfRec g_open_rec{};
-void gemm_profile_mark_begin(hipStream_t st, double flops, int key) {
+void gemm_profile_mark_begin(hipStream_t st, double flops, int key, double bytes) {
   if (!g_prof_on) return;
   g_open_rec.e0 = prof_event(); g_open_rec.e1 = prof_event();
-  g_open_rec.flops = flops; g_open_rec.key = key;
+  g_open_rec.flops = flops; g_open_rec.key = key; g_open_rec.bytes = bytes;
   (void)hipEventRecord(g_open_rec.e0, st);
 }
 void gemm_profile_mark_end(hipStream_t st) {
@@ -769,7 +771,7 @@ int gemm_profile_begin() {
   return DIC_OK;
 }
 
-int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out) {
+int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out, double* total_bytes) {
   g_prof_on = false;
   DIC_CHECK_HIP(hipDeviceSynchronize());
   std::map<int, int> slot;
@@ -782,8 +784,10 @@ int gemm_profile_end(int max_entries, int* keys, double* total_ms, double* total
     if (it == slot.end()) {
       if (n >= max_entries) continue;
       i = n++; slot[r.key] = i; keys[i] = r.key; total_ms[i] = 0; total_flops[i] = 0; launches[i] = 0;
+      if (total_bytes) total_bytes[i] = 0;
     } else i = it->second;
     total_ms[i] += ms; total_flops[i] += r.flops; launches[i] += 1;
+    if (total_bytes) total_bytes[i] += r.bytes;
   }
   for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
   g_prof_recs.clear();
@@ -941,6 +945,7 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
   if (g_prof_on) {
     rec.e0 = prof_event(); rec.e1 = prof_event();
     rec.flops = 2.0 * p.M * p.N * (double)p.K;
+    rec.bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);      // operands read once + output written once (fp32)
     rec.key = (dma_ok ? 1000 : 0) + (tile == 128 ? 100 : 0) + p.A.kind * 10 + p.B.kind;
     (void)hipEventRecord(rec.e0, st);
   }

@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(256) split_bf16x3_paired_kernel(const float* _
 
 // f16x2 format (top of the file), same row-pair interleaved layout: two planes of scale * x
 __global__ void __launch_bounds__(256) split_f16x2_paired_kernel(const float* __restrict__ x, long long rows, int K, float scale,
-                                                                  unsigned short* __restrict__ h1, unsigned short* __restrict__ h2) {
+                                                                  unsigned short* __restrict__ h1, unsigned short* __restrict__ h2,
+                                                                  unsigned* __restrict__ status) {
   const long long n4 = ((rows + 1) >> 1) * (K / 2);
   const int kb = K / 32;
   const long long stride = (long long)gridDim.x * 256;
@@ -83,6 +84,8 @@ __global__ void __launch_bounds__(256) split_f16x2_paired_kernel(const float* __
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rows) v = *reinterpret_cast<const float4*>(x + r * K + k);
     unsigned short a[4], b[4];
+    if (f16x2_out_of_range(v.x, scale) | f16x2_out_of_range(v.y, scale) | f16x2_out_of_range(v.z, scale) | f16x2_out_of_range(v.w, scale))
+      f16x2_raise(status);                // overflow guard (common.h)
     split2_f16(v.x, scale, a[0], b[0]); split2_f16(v.y, scale, a[1], b[1]);
     split2_f16(v.z, scale, a[2], b[2]); split2_f16(v.w, scale, a[3], b[3]);
     reinterpret_cast<uint2*>(h1)[i] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
@@ -115,6 +118,7 @@ struct Bf3Params {
   long long a_ld;
   int a_relu;
   int fmt;                      // operand format of A and B: 0 = bf16x3, 1 = f16x2 (ep.alpha then carries 1 / (scale_a * scale_b))
+  unsigned* status;             // f16x2 overflow guard word (common.h), nullable: raised by the producer waves of the on-the-fly operand
 };
 constexpr int OPK_ROWK_BN = 6;     // (A-operand kind of the kernel template; never stored in Bf3Operand::kind)
 constexpr int kBnTabMax = 2048;    // channels of the on-the-fly operand (its scale / shift table lives in LDS)
@@ -597,6 +601,16 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
         const f32x2_ a01 = f32x2_{x.x, x.y} * s01 + t01 + f32x2_{q.x, q.y}, a23 = f32x2_{x.z, x.w} * s23 + t23 + f32x2_{q.z, q.w};    // packed fp32 fma / add
         v[i][0] = fmaxf(a01.x, relu_floor); v[i][1] = fmaxf(a01.y, relu_floor);
         v[i][2] = fmaxf(a23.x, relu_floor); v[i][3] = fmaxf(a23.y, relu_floor);
+      }
+      if constexpr (FMT == 1) {
+        // overflow guard (common.h): the values are >= 0 here (a_relu) or at least no NaN survives fmaxf, so the largest of the
+        // sixteen decides - 8 vector instructions and a branch per slot instead of a compare per value
+        float mx = fmaxf(fmaxf(fabsf(v[0][0]), fabsf(v[0][1])), fabsf(v[0][2]));
+        mx = fmaxf(fmaxf(mx, fabsf(v[0][3])), fabsf(v[1][0])); mx = fmaxf(fmaxf(mx, fabsf(v[1][1])), fabsf(v[1][2]));
+        mx = fmaxf(fmaxf(mx, fabsf(v[1][3])), fabsf(v[2][0])); mx = fmaxf(fmaxf(mx, fabsf(v[2][1])), fabsf(v[2][2]));
+        mx = fmaxf(fmaxf(mx, fabsf(v[2][3])), fabsf(v[3][0])); mx = fmaxf(fmaxf(mx, fabsf(v[3][1])), fabsf(v[3][2]));
+        mx = fmaxf(mx, fabsf(v[3][3]));
+        if (mx > kF16Max / kF16ActScale) f16x2_raise(p.status);
       }
       if (__builtin_amdgcn_readfirstlane(S.flg) & 32u) {        // last M tile of a ragged matrix: rows past the end are zero
         asm volatile("" ::: "memory");                           // (keeps this a branch: 16 selects per slot otherwise)
@@ -1533,9 +1547,22 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       }
     }
   }
-  if (p.a_raw && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) return 1;      // on-the-fly operand: persistent 1x1 kernel or nothing
+  if (p.a_raw && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) {      // on-the-fly operand: persistent 1x1 kernel or nothing
+    if (!probe)      // (a caller that gets 1 takes the plane route; one that cannot - dic_debug_conv1x1_bn* - reports this text)
+      set_last_error("conv1x1 with on-the-fly BatchNorm operand: shape M=%d C=%d -> CO=%d is not eligible (the launch policy keeps it off "
+                     "the persistent 128x128 kernel: needs CO %% 128 == 0, C %% 32 == 0, C > 32 and enough output tiles to fill the CUs); "
+                     "nothing was launched", p.M, p.K, p.N);
+    return 1;
+  }
   if (probe) return DIC_OK;                 // conv1x1_bf3_bn_eligible: the decision only
-  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, (p.fmt == 1 ? 3000 : 2000) + (p.a_raw ? OPK_ROWK_BN : p.A.kind) * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)));
+  // algorithmic HBM bytes of the launch (bench.py roofline): every operand element read once, the output written once.  Plane operands
+  // cost 2 B per plane and element; an im2col A operand is its input image (each pixel read once, not once per tap); the on-the-fly
+  // operand reads the raw fp32 tensor (+ the residual) and may write the fp32 copy of its input
+  double abytes = (double)p.N * p.K * 2.0 * (p.fmt == 1 ? 2 : 3) + (double)p.M * p.N * 4.0;
+  if (p.a_raw) abytes += (double)p.M * p.K * 4.0 * (1 + (p.a_res ? 1 : 0) + (p.a_out ? 1 : 0));
+  else if (im) abytes += (double)(p.M / std::max(1, cg.OH * cg.OW)) * cg.H * cg.W * cg.C * 2.0 * (p.fmt == 1 ? 2 : 3);
+  else abytes += (double)p.M * p.K * 2.0 * (p.fmt == 1 ? 2 : 3);
+  gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, (p.fmt == 1 ? 3000 : 2000) + (p.a_raw ? OPK_ROWK_BN : p.A.kind) * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)), abytes);
   if (persist && (halo || !ws256) && (halo || g_bf3_ws) && g_bf3_ablate == 0) {      // the product's 128x128 kernels
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
@@ -1662,15 +1689,19 @@ bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs) {
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused, int fmt,
-                       float out_scale) {
+                       float out_scale, unsigned* status) {
   DIC_REQUIRE(raw && scale && shift && y && C % 32 == 0 && C <= kBnTabMax, "conv1x1_fwd_bf3_bn: C %% 32 == 0, C <= 2048");
-  if ((long long)M * C * 4 >= (1ll << 32)) return 1;        // the kernel addresses the input with 32-bit byte offsets
+  if ((long long)M * C * 4 >= (1ll << 32)) {                // the kernel addresses the input with 32-bit byte offsets
+    set_last_error("conv1x1 with on-the-fly BatchNorm operand: input of %d x %d floats exceeds 4 GiB (32-bit offsets); nothing was launched", M, C);
+    return 1;
+  }
   Bf3Params p{};
   p.M = M; p.N = CO; p.K = C;
   for (int i = 0; i < 3; ++i) { p.A.p[i] = nullptr; p.B.p[i] = w_planes[i]; }
   p.A.kind = OPK_ROWK; p.A.ld = C; p.A.paired = 1;
   p.B.kind = OPK_ROWK; p.B.ld = C; p.B.paired = 1;
   p.a_raw = raw; p.a_scale = scale; p.a_shift = shift; p.a_res = res; p.a_out = act_out; p.a_ld = C; p.a_relu = relu;
+  p.status = status;
   p.ep = ep_store(y, CO, nullptr, ACT_NONE);
   p.ep.stats = bn_partial;
   p.fmt = fmt;
@@ -1854,11 +1885,12 @@ int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* h
   return DIC_OK;
 }
 
-int split_f16x2_paired(const float* x, long long rows, int K, float scale, unsigned short* h1, unsigned short* h2, hipStream_t st) {
+int split_f16x2_paired(const float* x, long long rows, int K, float scale, unsigned short* h1, unsigned short* h2, hipStream_t st,
+                       unsigned* status) {
   DIC_REQUIRE(K % 32 == 0 && rows > 0 && scale > 0.f, "split_f16x2_paired: K %% 32, scale > 0");
   const long long n4 = ((rows + 1) >> 1) * (K / 2);
   const int blocks = (int)std::min<long long>((n4 + 255) / 256, 8192);
-  hipLaunchKernelGGL(split_f16x2_paired_kernel, dim3(blocks), dim3(256), 0, st, x, rows, K, scale, h1, h2);
+  hipLaunchKernelGGL(split_f16x2_paired_kernel, dim3(blocks), dim3(256), 0, st, x, rows, K, scale, h1, h2, status);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -1892,6 +1924,11 @@ int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi,
 int dic_split_f16x2_paired(const float* x, long long rows, int K, float scale, uint16_t* h1, uint16_t* h2, void* stream) {
   DIC_REQUIRE(x && h1 && h2 && rows > 0 && K > 0, "split_f16x2_paired: bad arguments");
   return split_f16x2_paired(x, rows, K, scale, h1, h2, (hipStream_t)stream);
+}
+int dic_split_f16x2_paired_checked(const float* x, long long rows, int K, float scale, uint16_t* h1, uint16_t* h2, uint32_t* overflow,
+                                   void* stream) {
+  DIC_REQUIRE(x && h1 && h2 && overflow && rows > 0 && K > 0, "split_f16x2_paired_checked: bad arguments");
+  return split_f16x2_paired(x, rows, K, scale, h1, h2, (hipStream_t)stream, overflow);
 }
 
 static int gemm_bf16x3_any(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,

@@ -18,7 +18,9 @@ struct BnBuf {
 size_t bn_finalize_ws_doubles(long long max_mtiles, int C);
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, BnBuf out, double* red,
-                      hipStream_t st);
+                      hipStream_t st, unsigned* status = nullptr)   /* status (nullable): raised when a channel's statistics are not finite
+                                                                      (an inf / NaN reached the convolution output); that channel's running
+                                                                      statistics are then left untouched */;
 // eval mode: scale/shift from the running statistics
 int bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, BnBuf out, hipStream_t st);
@@ -29,11 +31,15 @@ int bn_apply(const float* x, const float* residual, float* y, long long rows, in
 // the residual may be given as fp32 or as planes of the same layout (reconstructed exactly as (hi + mid) + lo)
 int bn_apply_planes(const float* x, const float* residual, const unsigned short* const residual_planes[3], float* y,
                     unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st,
-                    const BnBuf* residual_bn = nullptr)   /* residual_bn: the fp32 residual is raw, apply this affine first */;
+                    const BnBuf* residual_bn = nullptr   /* residual_bn: the fp32 residual is raw, apply this affine first */,
+                    unsigned* status = nullptr)          /* f16x2 planes (planes[2] == NULL): overflow guard word (common.h) */;
 // y[b,ph,pw,c] = max over kxk window (stride s, pad p) of act(x*scale+shift); idx (nullable) = kh*k+kw of the max
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
                     float* y, unsigned char* idx, hipStream_t st,
-                    unsigned short* const planes[3] = nullptr)   /* optional: also/only paired bf16x3 planes (y may be null then) */;
+                    unsigned short* const planes[3] = nullptr   /* optional: also/only paired bf16x3 planes (y may be null then) */,
+                    unsigned* status = nullptr)                  /* f16x2 planes: overflow guard word */;
+// y[0..n) = NaN if *status != 0 (the loud end of the f16x2 overflow guard: one small launch, returns at once otherwise)
+int poison_if_raised(float* y, long long n, const unsigned* status, hipStream_t st);
 // adaptive average pooling of an NHWC map to OUTxOUT (AdaptiveAvgPool2d(14): exact 2x2 replication for 7x7)
 // with optional fused BN+ReLU on load
 int adaptive_avgpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int out, float* y,

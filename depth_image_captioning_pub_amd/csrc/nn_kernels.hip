@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_train_kernel(const float* __
                                                                   double count, int C, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta,
                                                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                  BnBuf out) {
+                                                                  BnBuf out, unsigned* __restrict__ status) {
   __shared__ double s1[32][33], s2[32][33];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -62,7 +62,11 @@ __global__ void __launch_bounds__(1024) bn_finalize_train_kernel(const float* __
     out.shift[c] = beta[c] - (float)mean * sc;
     out.mean[c] = (float)mean;
     out.invstd[c] = invstd;
-    if (rmean) {
+    // an inf / NaN in the convolution output (an overflowed f16x2 plane upstream, a non-finite input image) shows here as non-finite
+    // sums: raise the guard word and keep the running statistics of this channel as they were
+    const bool finite = fabs(a) <= 1.7e308 && fabs(b) <= 1.7e308;
+    if (!finite) f16x2_raise(status);
+    if (rmean && finite) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
       rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
       rvar[c] = (1.f - kBnMomentum) * rvar[c] + kBnMomentum * (float)unb;
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256) bn_finalize_from_slices_kernel(const doub
                                                                        const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta,
                                                                        float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                       BnBuf out) {
+                                                                       BnBuf out, unsigned* __restrict__ status) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double a = 0.0, b = 0.0;
@@ -140,7 +144,9 @@ __global__ void __launch_bounds__(256) bn_finalize_from_slices_kernel(const doub
   out.shift[c] = beta[c] - (float)mean * sc;
   out.mean[c] = (float)mean;
   out.invstd[c] = invstd;
-  if (rmean) {
+  const bool finite = fabs(a) <= 1.7e308 && fabs(b) <= 1.7e308;      // (see bn_finalize_train_kernel)
+  if (!finite) f16x2_raise(status);
+  if (rmean && finite) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
     rvar[c] = (1.f - kBnMomentum) * rvar[c] + kBnMomentum * (float)unb;
@@ -152,15 +158,15 @@ size_t bn_finalize_ws_doubles(long long max_mtiles, int C) {
 }
 
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma, const float* beta,
-                      float* running_mean, float* running_var, BnBuf out, double* red, hipStream_t st) {
+                      float* running_mean, float* running_var, BnBuf out, double* red, hipStream_t st, unsigned* status) {
   if (mtiles > 512 && red != nullptr) {
     const int slices = ceil_div(mtiles, kBnSliceTiles);
     hipLaunchKernelGGL(bn_stats_slice_kernel, dim3(ceil_div(C, 32), slices), dim3(256), 0, st, partial, mtiles, C, red);
     hipLaunchKernelGGL(bn_finalize_from_slices_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)red,
-                       slices, (double)count, C, gamma, beta, running_mean, running_var, out);
+                       slices, (double)count, C, gamma, beta, running_mean, running_var, out, status);
   } else {
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, st, partial, mtiles,
-                       (double)count, C, gamma, beta, running_mean, running_var, out);
+                       (double)count, C, gamma, beta, running_mean, running_var, out, status);
   }
   DIC_LAUNCH_CHECK();
   return DIC_OK;
@@ -216,7 +222,7 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
                                                                unsigned short* __restrict__ mid,
                                                                unsigned short* __restrict__ lo, long long rows, int C,
                                                                BnBuf bn, int relu, const float* __restrict__ rscale,
-                                                               const float* __restrict__ rshift) {
+                                                               const float* __restrict__ rshift, unsigned* __restrict__ status) {
   // one thread = 8 channels of one pixel: 2 x 16-B loads in, one 16-B store per plane out; 8 consecutive threads
   // produce one 128-B plane line (4 threads per pixel of the pair)
   const long long n8 = ((rows + 1) >> 1) * (C / 4);
@@ -269,6 +275,10 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
     unsigned short h[8], m[8], l[8];
 #define DIC_PK(A_, Q_) ((unsigned)A_[Q_] | ((unsigned)A_[Q_ + 1] << 16))
     if (!lo) {      // f16x2 format (gemm_bf3.hip): two fp16 planes of kF16ActScale * v
+      bool bad = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bad |= f16x2_out_of_range(v[q], kF16ActScale);
+      if (bad) f16x2_raise(status);
 #pragma unroll
       for (int q = 0; q < 8; ++q) split2_f16(v[q], kF16ActScale, h[q], m[q]);
       reinterpret_cast<uint4*>(hi)[i] = make_uint4(DIC_PK(h, 0), DIC_PK(h, 2), DIC_PK(h, 4), DIC_PK(h, 6));
@@ -286,7 +296,7 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const float* __res
 
 int bn_apply_planes(const float* x, const float* residual, const unsigned short* const residual_planes[3], float* y,
                     unsigned short* const planes[3], long long rows, int C, BnBuf bn, int relu, hipStream_t st,
-                    const BnBuf* residual_bn) {
+                    const BnBuf* residual_bn, unsigned* status) {
   DIC_REQUIRE(!residual_bn || residual, "bn_apply_planes: residual_bn needs an fp32 residual");
   DIC_REQUIRE(!(residual && residual_planes), "bn_apply_planes: give the residual as fp32 or as planes, not both");
   DIC_REQUIRE(C % 32 == 0, "bn_apply_planes: C %% 32");
@@ -297,7 +307,7 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
   const unsigned short* r2 = residual_planes ? residual_planes[2] : nullptr;
   hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, x, residual, r0, r1, r2, y, planes[0],
                      planes[1], planes[2], rows, C, bn, relu, residual_bn ? residual_bn->scale : nullptr,
-                     residual_bn ? residual_bn->shift : nullptr);
+                     residual_bn ? residual_bn->shift : nullptr, status);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -311,7 +321,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
                                                                unsigned char* __restrict__ idx,
                                                                unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
-                                                               unsigned short* __restrict__ lo) {
+                                                               unsigned short* __restrict__ lo, unsigned* __restrict__ status) {
   const long long total = (long long)B * PH * PW * C4;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
@@ -350,6 +360,8 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
       const long long off = plane_offset(row, c4 * 4, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
       if (!lo) {    // f16x2 format: two fp16 planes of kF16ActScale * v
+        if (f16x2_out_of_range(best.x, kF16ActScale) | f16x2_out_of_range(best.y, kF16ActScale) | f16x2_out_of_range(best.z, kF16ActScale) |
+            f16x2_out_of_range(best.w, kF16ActScale)) f16x2_raise(status);
         split2_f16(best.x, kF16ActScale, h[0], m[0]); split2_f16(best.y, kF16ActScale, h[1], m[1]);
         split2_f16(best.z, kF16ActScale, h[2], m[2]); split2_f16(best.w, kF16ActScale, h[3], m[3]);
       } else {
@@ -364,7 +376,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
 }
 
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
-                    float* y, unsigned char* idx, hipStream_t st, unsigned short* const planes[3]) {
+                    float* y, unsigned char* idx, hipStream_t st, unsigned short* const planes[3], unsigned* status) {
   DIC_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
   DIC_REQUIRE(y || planes, "maxpool: no output");
   DIC_REQUIRE(!planes || C % 32 == 0, "maxpool: plane output needs C %% 32");
@@ -373,7 +385,19 @@ int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn,
   BnBuf z{};
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, B, H, W, C / 4, bn ? *bn : z,
                      bn ? 1 : 0, relu, k, s, p, PH, PW, y, idx, planes ? planes[0] : nullptr, planes ? planes[1] : nullptr,
-                     planes ? planes[2] : nullptr);
+                     planes ? planes[2] : nullptr, status);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// the loud end of the f16x2 overflow guard (common.h): every element of y becomes NaN when the status word is raised
+__global__ void __launch_bounds__(256) poison_if_raised_kernel(float* __restrict__ y, long long n, const unsigned* __restrict__ status) {
+  if (*status == 0u) return;
+  const float nan = __uint_as_float(0x7fc00000u);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = nan;
+}
+int poison_if_raised(float* y, long long n, const unsigned* status, hipStream_t st) {
+  hipLaunchKernelGGL(poison_if_raised_kernel, dim3(64), dim3(256), 0, st, y, n, status);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

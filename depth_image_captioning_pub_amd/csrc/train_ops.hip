@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(256) pack_targets_kernel(const long long* __re
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, long long n,
                                                      float decay, float beta1, float beta2, float step_size,
-                                                     float inv_bc2_sqrt, float eps) {
+                                                     float inv_bc2_sqrt, float eps, const unsigned* __restrict__ skip_if_raised) {
+  if (skip_if_raised && *skip_if_raised != 0u) return;       // f16x2 overflow guard (dic.h): parameters and moments stay as they are
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float gi = g[i];
@@ -208,11 +209,18 @@ int dic_pack_targets(const int64_t* captions, int cap_stride, const int* dec_len
 
 int dic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  return dic_adamw_step_guarded(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream);
+}
+
+int dic_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, const uint32_t* skip_if_raised,
+                           void* stream) {
   DIC_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adamw: bad arguments");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                     n, 1.0f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
+                     n, 1.0f - lr * weight_decay, beta1, beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps,
+                     (const unsigned*)skip_if_raised);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -34,7 +34,7 @@ class DptRunner:
         split-bf16 kernels (fp32-accurate: three bf16 planes per operand, six MFMA products); "fp32" keeps them
         on the exact-fp32 MFMA kernels (the 3-channel stem and the pointwise head always are); "f16x2" runs the same layers on the
         two-plane fp16 operand format (three products, half the matrix-core work; weights scaled per layer so that their largest
-        magnitude lands in [2^14, 2^15), activations by 4: a layer input beyond +-16376 would overflow to inf)."""
+        magnitude lands in (2^13, 2^14], activations by 4: a layer input beyond +-16376 would overflow to inf)."""
         if arith not in ("bf16x3", "f16x2", "fp32"):
             raise _lib.DicError("DptRunner: arith must be 'bf16x3', 'f16x2' or 'fp32'")
         self.arith = arith
@@ -76,6 +76,10 @@ class DptRunner:
         self.w_scale: Dict[str, float] = {}                 # f16x2: the power of two each weight matrix was scaled by
         self.x_planes: Optional[list] = None                # scratch planes of the current layer's input
         self.tail_ws: Optional[torch.Tensor] = None
+        # f16x2 overflow guard: every split of a layer input (dic_split_f16x2_paired_checked) raises this word when a value does not
+        # fit the fp16 planes; forward() clears it first and reads it last (downstream ReLUs turn the NaN of an overflowed product
+        # into 0, so looking at the output's values alone would miss it)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
     # ---- split-bf16 operands ---------------------------------------------------------------------
     ACT_SCALE = 4.0                                          # f16x2: activation planes hold 4 * x
@@ -86,8 +90,8 @@ class DptRunner:
         if out is None or out[0].numel() < n:
             out = [torch.empty(n, dtype=torch.int16, device=self.dev) for _ in range(3)]
         if self.arith == "f16x2":
-            check(self.lib.dic_split_f16x2_paired(ptr(x2d), C.c_longlong(rows), k, C.c_float(scale), ptr(out[0]), ptr(out[1]), stream_ptr()),
-                  "dic_split_f16x2_paired")
+            check(self.lib.dic_split_f16x2_paired_checked(ptr(x2d), C.c_longlong(rows), k, C.c_float(scale), ptr(out[0]), ptr(out[1]),
+                                                          ptr(self.overflow), stream_ptr()), "dic_split_f16x2_paired_checked")
             return out
         check(self.lib.dic_split_bf16x3_paired(ptr(x2d), C.c_longlong(rows), k, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()),
               "dic_split_bf16x3_paired")
@@ -318,6 +322,7 @@ class DptRunner:
         if c != 3 or H != W or H % 32:
             raise _lib.DicError("DptRunner.forward: images must be [B,3,S,S] with S a multiple of 32")
         cfg, P = self.cfg, "pretrained.model."
+        self.overflow.zero_()
         stages = self.backbone(x)
         gh, gw = H // 16, W // 16
         tok = self.linear(stages[-1], P + "patch_embed.proj")                       # HybridEmbed.proj (1x1) -> [B,gh,gw,C]
@@ -346,11 +351,12 @@ class DptRunner:
         check(self.lib.dic_pointwise_dot(ptr(y), C.c_longlong(B * H * W), y.shape[-1], ptr(self.w["scratch.output_conv.4.weight"]),
                                          ptr(self.w["scratch.output_conv.4.bias"]), 1, ptr(out), stream_ptr()),
               "dic_pointwise_dot")
-        if self.arith == "f16x2" and not bool(torch.isfinite(out).all()):
-            # (the reference's post-processing maps NaN to 0.5: an overflow must not pass silently.  The estimator runs in epoch 0
-            #  only, one host synchronisation per batch is not on any hot path.)
-            raise _lib.DicError("DptRunner: non-finite depth map in f16x2 arithmetic - a layer input exceeded the fp16 range "
-                                "(+-16376 after the activation scale); use arith='bf16x3' for these weights")
+        if self.arith == "f16x2" and (int(self.overflow.item()) != 0 or not bool(torch.isfinite(out).all())):
+            # (the reference's post-processing maps NaN to 0.5, and the ReLUs on the way turn the NaN of an overflowed product into 0:
+            #  the guard word raised by the split kernels is what sees it.  The estimator runs in epoch 0 only, one host
+            #  synchronisation per batch is not on any hot path.)
+            raise _lib.DicError("DptRunner: a layer input exceeded the fp16 range of the f16x2 operand planes (|x| > 16376) or was not "
+                                "finite - the depth map of this batch is invalid; use arith='bf16x3' for these weights")
         return out
 
     def flops_per_image(self, size: int = 384) -> float:

@@ -182,7 +182,9 @@ class CaptionTrainer:
                  depth_init: Optional[Dict[str, torch.Tensor]] = None,
                  depth_state: Optional[Dict[str, torch.Tensor]] = None,
                  resnet_init: Optional[Dict[str, torch.Tensor]] = None,
-                 process_group=None, conv_mode: str = "fp32", use_depth: bool = True):
+                 process_group=None, conv_mode: Optional[str] = None, use_depth: bool = True):
+        """conv_mode: arithmetic of the frozen ResNet-152's convolutions - None = native.DEFAULT_CONV_MODE ("f16x2", the mode
+        bench.py measures); "bf16x3" / "fp32" are the exact-operand alternatives (no range limit, ~1.4x / ~2.3x the step time)."""
         if not torch.cuda.is_available():
             raise DicError("CaptionTrainer needs a GPU: the product path has no CPU fallback")
         self.device = torch.device(device)
@@ -217,7 +219,17 @@ class CaptionTrainer:
             n = self.rn_w[k].numel()
             self.rn_w[k] = self.rn_stats[o:o + n]
             o += n
-        self.resnet = native.ResNetRunner(self.rn_w, resnet_layers, conv_mode=conv_mode)
+        self.conv_mode = conv_mode or native.DEFAULT_CONV_MODE
+        self.resnet = native.ResNetRunner(self.rn_w, resnet_layers, conv_mode=self.conv_mode)
+        # f16x2 overflow guard (include/dic.h, dic_resnet_fwd): `guard` holds the status word of the forward whose features the
+        # current step consumes.  AdamW and the BatchNorm running-statistic update take it as their skip word, so a step whose
+        # features overflowed the fp16 operand planes changes nothing - without the host looking at the word first.  The host
+        # learns of it asynchronously: after every update the word is copied into a pinned ring (no synchronisation) and polled at
+        # the start of the following steps / in check_status(), which raise DicError.
+        self.guard = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._guard_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self._guard_pending: List[tuple] = []      # (ring slot, event, step number) of copies in flight
+        self._guard_slot = 0
         self.step_count = 0
         self.depth_fwd_count = 0       # train-mode depth-encoder forwards (= BatchNorm num_batches_tracked)
         self.rng_offset = 0
@@ -322,7 +334,8 @@ class CaptionTrainer:
                 return None
         _, slot, done = self.queue.pop(0)
         torch.cuda.current_stream().wait_event(done)
-        native.bn_ema_update(self.rn_stats, slot.delta, 0.1)
+        self._guard_take(slot.runner)
+        native.bn_ema_update(self.rn_stats, slot.delta, 0.1, skip_if_raised=self.guard)      # (a flagged forward's statistics are dropped)
         self.resnet.train_forwards += 1
         # the slot is free for the next prefetch from here on (train_step launches it before this step has read the
         # features), so the step works on its own copy: one 26-MB device copy (~10 us), ordered on this stream before the
@@ -340,6 +353,47 @@ class CaptionTrainer:
         if self.side_done is not None:
             torch.cuda.current_stream().wait_event(self.side_done)
         return self.resnet.forward(imgs, train_bn=train_bn, compact=compact)
+
+    # ---- f16x2 overflow guard -------------------------------------------------------------------
+    def _guard_take(self, runner: Optional[native.ResNetRunner]) -> None:
+        """`guard` <- the status word of the forward that produced this step's features (None / exact modes: clear)."""
+        if runner is not None and runner.mode == 2 and runner.workspace is not None:
+            self.guard.copy_(runner.status_word(), non_blocking=True)
+        else:
+            self.guard.zero_()
+
+    def _guard_publish(self) -> None:
+        """Copy the word to the host ring (asynchronous) after the update of this step has been enqueued."""
+        if self.conv_mode != "f16x2":
+            return
+        if len(self._guard_pending) >= self._guard_host.numel():      # ring full (16 steps un-polled): settle the oldest first
+            self._guard_poll(block=True)
+        i = self._guard_slot
+        self._guard_slot = (i + 1) % self._guard_host.numel()
+        self._guard_host[i:i + 1].copy_(self.guard, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._guard_pending.append((i, ev, self.step_count))
+
+    def _guard_poll(self, block: bool = False) -> None:
+        bad = []
+        while self._guard_pending and (block or self._guard_pending[0][1].query()):
+            i, ev, step = self._guard_pending.pop(0)
+            ev.synchronize()
+            if int(self._guard_host[i]) != 0:
+                bad.append(step)
+        if bad:
+            self.step_count -= len(bad)        # the device skipped those updates: Adam's bias correction must not count them
+            raise DicError(f"f16x2 overflow guard: the ResNet-152 forward of optimiser step(s) {bad} produced an activation beyond the "
+                           "fp16 range of the operand planes (|x| > 16376) or a non-finite value; its features were NaN and AdamW was "
+                           "skipped on the device for those steps, so parameters, Adam moments and BatchNorm running statistics are "
+                           "as they were before them.  Re-create the trainer with conv_mode='bf16x3' (exact operands, no range limit)")
+
+    def check_status(self) -> None:
+        """Synchronise with the device and raise DicError if any step since the last check tripped the f16x2 overflow guard.
+        Call it wherever the loss is read on the host (the reference reads it every iteration, depth_train.py:224)."""
+        torch.cuda.current_stream().synchronize()
+        self._guard_poll(block=True)
 
     # ---- pieces -----------------------------------------------------------------------------
     def _compact(self, imgs, depth_map) -> bool:
@@ -366,7 +420,10 @@ class CaptionTrainer:
                    apply_update: bool = True, virtual_world: Optional[int] = None) -> torch.Tensor:
         """One iteration of depth_train.py:168-221. Returns the loss as a 1-element device tensor (no host sync).
         next_imgs: images of the following batch, or the list [batch i+1, batch i+2, ...] of the next batches in order; their
-          (frozen) ResNet forwards run ahead on side streams, up to `prefetch_depth` (3) at a time.
+          (frozen) ResNet forwards run ahead on side streams, up to `prefetch_depth` (3) at a time.  A prefetched forward is
+          matched to a later train_step by OBJECT IDENTITY of the images tensor: pass the very tensor objects announced here
+          (not a re-wrapped copy, slice or .to() result of them), in the announced order - otherwise the pending forwards ahead
+          of the batch are discarded (RuntimeWarning, counted in `prefetch_dropped`) and the step runs its own forward.
         global_tokens: packed tokens (sum of lengths-1) of the GLOBAL batch when data parallel with variable-length
           captions; default = this rank's count x world size (exact for equal-length batches such as bench.py's).
         apply_update=False leaves the (scaled, all-reduced) gradients in self.flat.grad and skips AdamW;
@@ -374,6 +431,7 @@ class CaptionTrainer:
           reproduce an N-rank step shard by shard (tests)."""
         B = imgs.shape[0] if imgs is not None else precomputed_features.shape[0]
         tmax = max(lengths) - 1
+        self._guard_poll()              # (non-blocking) an earlier step tripped the f16x2 overflow guard -> DicError
         self.marks = []
         self._mark("start")
         if precomputed_features is None:
@@ -383,6 +441,7 @@ class CaptionTrainer:
                 compact = feats.shape[1] == native.L_COMPACT
             else:
                 feats = self._resnet_eager(imgs, True, compact)                             # depth_train.py:179
+                self._guard_take(self.resnet)
             if next_imgs is not None:       # one upcoming batch, or the list of the next `prefetch_depth` batches in order
                 upcoming = list(next_imgs) if isinstance(next_imgs, (list, tuple)) else [next_imgs]
                 for k, nxt in enumerate(upcoming[:self.prefetch_depth]):
@@ -391,6 +450,7 @@ class CaptionTrainer:
             self._mark("resnet152_fwd")
         else:                                       # decoder/depth-encoder-only step (tests)
             feats = precomputed_features
+            self._guard_take(None)
             compact = feats.shape[1] == native.L_COMPACT
         fdep = dtape = None
         if self.use_depth:
@@ -438,7 +498,8 @@ class CaptionTrainer:
         """AdamW on the flat buffer with whatever self.flat.grad holds (depth_train.py:221)."""
         self.step_count += 1
         native.adamw_step(self.flat.data, self.flat.grad, self.flat.exp_avg, self.flat.exp_avg_sq, self.step_count,
-                          lr=self.lr)
+                          lr=self.lr, skip_if_raised=self.guard)
+        self._guard_publish()
 
     @torch.no_grad()
     def eval_loss(self, imgs, depth_map, captions, lengths, gumbel_u: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -12,6 +12,9 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 L_CELLS, D_ENC, D_ATT, D_EMB, D_HID = 196, 2048, 128, 128, 128
+# Arithmetic of the frozen ResNet-152's convolutions everywhere a caller does not choose one (ResNetRunner, engine.CaptionTrainer, the
+# CNNEncoder_Atten shim, ConfigTrain.conv_mode, bench.py): the benchmarked mode.  "bf16x3" / "fp32" are the exact-operand alternatives.
+DEFAULT_CONV_MODE = "f16x2"
 L_COMPACT = 49          # distinct annotation cells when the 14x14 grid is a 2x2 replication of a 7x7 map (Q3)
 
 # state_dict key  ->  field of dic_decoder_weights / dic_decoder_grads (include/dic.h)
@@ -207,25 +210,37 @@ def caption_loss(logits: torch.Tensor, targets: torch.Tensor, alphas: Optional[t
     return loss, dlogits, dalphas
 
 
+def _guard_ptr(word: Optional[torch.Tensor]):
+    if word is None:
+        return C.c_void_p(0)
+    if not (word.is_cuda and word.dtype == torch.int32 and word.numel() >= 1 and word.is_contiguous()):
+        raise _lib.DicError("the overflow guard word must be a contiguous int32 GPU tensor")
+    return ptr(word)
+
+
 def adamw_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
                lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-               weight_decay: float = 0.01) -> None:
+               weight_decay: float = 0.01, skip_if_raised: Optional[torch.Tensor] = None) -> None:
+    """dic_adamw_step_guarded: `skip_if_raised` (int32 device word, optional) = the f16x2 overflow guard of the forward behind these
+    gradients; when it is non-zero the kernel leaves parameters and moments untouched."""
     lib = _lib.load()
     for t in (params, grads, exp_avg, exp_avg_sq):
         if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
             raise _lib.DicError("adamw_step needs contiguous fp32 GPU buffers")
-    rc = lib.dic_adamw_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), C.c_longlong(params.numel()), step,
-                            C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
-                            stream_ptr())
-    check(rc, "dic_adamw_step")
+    rc = lib.dic_adamw_step_guarded(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), C.c_longlong(params.numel()), step,
+                                    C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
+                                    _guard_ptr(skip_if_raised), stream_ptr())
+    check(rc, "dic_adamw_step_guarded")
 
 
-def bn_ema_update(running: torch.Tensor, delta: torch.Tensor, momentum: float = 0.1) -> None:
-    """dic_bn_ema_update: running = (1 - momentum) * running + delta (flat fp32 buffers of equal length)."""
+def bn_ema_update(running: torch.Tensor, delta: torch.Tensor, momentum: float = 0.1,
+                  skip_if_raised: Optional[torch.Tensor] = None) -> None:
+    """dic_bn_ema_update_guarded: running = (1 - momentum) * running + delta (flat fp32 buffers of equal length), dropped on the
+    device when the guard word `skip_if_raised` is non-zero."""
     if not (running.is_cuda and running.is_contiguous() and delta.is_contiguous() and running.numel() == delta.numel()):
         raise _lib.DicError("bn_ema_update needs two contiguous GPU buffers of equal length")
-    check(_lib.load().dic_bn_ema_update(ptr(running), ptr(delta), C.c_longlong(running.numel()), C.c_float(momentum),
-                                        stream_ptr()), "dic_bn_ema_update")
+    check(_lib.load().dic_bn_ema_update_guarded(ptr(running), ptr(delta), C.c_longlong(running.numel()), C.c_float(momentum),
+                                                _guard_ptr(skip_if_raised), stream_ptr()), "dic_bn_ema_update_guarded")
 
 
 def dropout_mask(shape, p: float, seed: int, offset: int, device) -> torch.Tensor:
@@ -356,14 +371,15 @@ class ResNetRunner:
     """Holds the OHWI copies of the (frozen) ResNet conv weights and the layer table for dic_resnet_fwd.
     `tensors` is keyed like CNNEncoder_Atten.state_dict() ('backbone.0.weight', 'backbone.1.running_mean', ...)."""
 
-    def __init__(self, tensors: Dict[str, torch.Tensor], layers: Sequence[int] = (3, 8, 36, 3), conv_mode: str = "fp32"):
+    def __init__(self, tensors: Dict[str, torch.Tensor], layers: Sequence[int] = (3, 8, 36, 3), conv_mode: str = DEFAULT_CONV_MODE):
         """conv_mode "fp32": exact-fp32 MFMA convolutions; "bf16x3": fp32-accurate split-bf16 convolutions
         (each fp32 weight/activation = hi+mid+lo bf16 exactly, 6 products; csrc/gemm_bf3.hip); "f16x2": the same kernels on two
         fp16 planes of scaled values (3 products: half the matrix-core work, a few fp32 round-offs per product - inside the error
         envelope of an fp32 evaluation of the network; weights scaled per layer so that their largest magnitude lands in
-        [2^14, 2^15), activations by 4)."""
+        (2^13, 2^14] - scale = 2^floor(14 - log2 max|w|) -, activations by 4)."""
         from .synthetic import resnet152_spec
         lib = _lib.load()
+        _lib.check_struct(lib, 0, ConvBnLayer)
         if conv_mode not in CONV_MODES:
             raise _lib.DicError(f"conv_mode must be one of {list(CONV_MODES)}")
         self.mode = CONV_MODES[conv_mode]
@@ -468,6 +484,22 @@ class ResNetRunner:
         if train_bn and not torch.cuda.is_current_stream_capturing():
             self.train_forwards += 1
         return out
+
+    # ---- f16x2 overflow guard (include/dic.h, dic_resnet_fwd): the status word is the first 4 bytes of the workspace -------------
+    def status_word(self) -> torch.Tensor:
+        """int32[1] device view of the status word of this runner's last forward (non-zero: an activation left the fp16 range of the
+        f16x2 operand planes, or a non-finite value reached a convolution output; the features were filled with NaN)."""
+        if self.workspace is None:
+            raise _lib.DicError("ResNetRunner.status_word: no forward has run yet")
+        return self.workspace[:4].view(torch.int32)
+
+    def check_overflow(self) -> None:
+        """Synchronising check of the last forward (one 4-byte read): raises DicError when its guard word is raised."""
+        if self.mode == 2 and self.workspace is not None and int(self.status_word().item()) != 0:
+            raise _lib.DicError("ResNet-152 forward in f16x2 arithmetic: an activation exceeded the fp16 range of the operand planes "
+                                "(|x| > 16376) or a non-finite value reached a convolution - the features were filled with NaN and the "
+                                "BatchNorm running statistics of the affected layers left untouched; use conv_mode='bf16x3' (exact "
+                                "operands, no range limit) for these weights / inputs")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -28,8 +28,18 @@ extern "C" {
 #define DIC_E 128      /* dim_embedding              (config.py:13) */
 #define DIC_H 128      /* dim_hidden                 (config.py:15) */
 
+/* ABI version of this header.  dic_version() returns the value the library was built with: a binding compares the two before its
+ * first call (the Python loader does, depth_image_captioning_pub_amd/_lib.py).  History: 100 = rounds 1-2; 200 (round 4) = the
+ * dic_conv_bn_layer struct of round 3 (w_hi / w_mid / w_lo / w_scale: 72 bytes), dic_vit_attention with (workspace, workspace_bytes),
+ * the f16x2 overflow guard (status word at offset 0 of the ResNet workspace, dic_*_guarded, dic_split_f16x2_paired_checked),
+ * dic_struct_bytes. */
+#define DIC_ABI_VERSION 200
 int dic_version(void);
 const char* dic_last_error(void);
+/* sizeof() of the structs of this header as the library sees them, for bindings that mirror them by hand (ctypes.Structure, cgo, JNI):
+ * which 0 dic_conv_bn_layer, 1 dic_decoder_weights, 2 dic_decoder_grads, 3 dic_depth_encoder_weights, 4 dic_depth_encoder_grads,
+ * 5 dic_depth_bn_state; 0 for an unknown index. */
+size_t dic_struct_bytes(int which);
 
 /* ---- generic exact-fp32 MFMA contraction (building block; replaces the aten::addmm / aten::mm
  *      calls under every nn.Linear of the path, e.g. attention.py:84-87, depth_models.py:167,189,197)
@@ -159,6 +169,13 @@ int dic_pack_targets(const int64_t* captions, int cap_stride, const int* dec_len
  *      `step` is the 1-based step number. */
 int dic_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* The same step, skipped ON THE DEVICE (parameters and both moments untouched) when the device word *skip_if_raised is non-zero
+ * (NULL = dic_adamw_step).  Hand it the f16x2 overflow guard word of the forward that produced the gradients (dic_resnet_fwd,
+ * below): a step whose features overflowed the fp16 operand planes then leaves the optimiser state as it was, without the host
+ * having to look at the word before enqueueing the update. */
+int dic_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, const uint32_t* skip_if_raised,
+                           void* stream);
 
 /* ---- data parallel (the reference itself is single-GPU, config.py:68): the path has ONE exchange step, a
  *      sum all-reduce of the flat gradient buffer between dic_decoder_bwd / dic_depth_encoder_bwd and dic_adamw_step.  The
@@ -175,6 +192,12 @@ int dic_comm_create(const void* id128, int nranks, int rank, dic_comm** out);
 int dic_allreduce_grads(dic_comm* comm, float* flat_grad, long long count, void* stream);
 int dic_comm_ranks(const dic_comm* comm, int* nranks, int* rank);
 int dic_comm_destroy(dic_comm* comm);
+/* Which RCCL the entry points above bound: "rccl=<path of the shared object>;reused ..." when the process already held one (e.g.
+ * PyTorch's own librccl.so: that copy is used, so both see the same communicator state) or ";loaded by libdic_hip.so ..." when this
+ * library had to dlopen one.  Two different paths in one process (torch's and this one) would mean two RCCL instances: check here.
+ * STATUS: the multi-rank path of dic_comm_create / dic_allreduce_grads has only ever executed with ONE rank on hardware (the build
+ * pool has 1-GPU boxes); N > 1 is covered over gloo on CPU (tests/test_dp_gloo_cpu.py) and is unverified over RCCL. */
+int dic_comm_info(char* buf, size_t bytes);
 
 /* ---- dropout multiplier (nn.Dropout(p) in train mode, depth_models.py:119,197): out[i] = 0 or 1/(1-p),
  *      Philox4x32-10 counter-based stream keyed by (seed, offset). */
@@ -244,7 +267,7 @@ typedef struct dic_conv_bn_layer {
                                           * planes of dic_split_f16x2_paired(w, scale = w_scale), w_lo NULL (layer 0, the stem, keeps its
                                           * bf16x3 strip planes in both modes); mode 0: NULL */
   float w_scale;                         /* mode 2 only: the power of two the weight planes were scaled by (largest |w| * w_scale in
-                                          * [2^14, 2^15)) */
+                                          * (2^13, 2^14]: w_scale = 2^floor(14 - log2 max|w|)) */
 } dic_conv_bn_layer;
 
 int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW, void* stream);
@@ -263,7 +286,13 @@ size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mo
  * layer but the C_in=3 stem), same results to fp32 rounding level, ~1.4x the conv throughput at batch 64; mode 2: the same
  * kernels on the f16x2 operand format (two fp16 planes of scaled values, three products; dic_split_f16x2_paired): errors of a few
  * fp32 round-offs per product, inside the envelope of an fp32 evaluation of the network (tests/test_encoders_gpu.py), half the
- * matrix-core work.  Activations are scaled by 4: an activation beyond +-16376 turns the output into inf/NaN. */
+ * matrix-core work.  Activations are scaled by 4, so a layer input beyond +-16376 does not fit the fp16 planes.
+ * OVERFLOW GUARD (mode 2): the first 4 bytes of `workspace` are a status word (uint32).  Every forward clears it first; every kernel
+ * that writes f16x2 planes raises it when a value is out of range or not finite, and the BatchNorm statistics kernels raise it on
+ * non-finite sums.  When it is raised at the end of the forward, `features` is filled with NaN (the values could otherwise look sane:
+ * ReLU turns the NaN of an overflowed product into 0) and the BatchNorm running statistics of the affected channels were left
+ * untouched.  A caller reads the word when it next synchronises, or hands its address to dic_adamw_step_guarded /
+ * dic_bn_ema_update_guarded so that the step is dropped on the device; the remedy is mode 1 (bf16x3: exact operands, no range limit). */
 int dic_resnet_fwd(const dic_conv_bn_layer* layers, int n_layers, const int* blocks, const float* imgs_nchw, int B,
                    int H, int W, int train_bn, int mode, float* features, void* workspace, size_t workspace_bytes,
                    void* stream);
@@ -282,10 +311,15 @@ int dic_split_bf16x3(const float* x, long long n, uint16_t* hi, uint16_t* mid, u
 int dic_split_bf16x3_paired(const float* x, long long rows, int K, uint16_t* hi, uint16_t* mid, uint16_t* lo,
                             void* stream);
 /* "f16x2" operand format of the same kernels: two fp16 planes h1 + h2 of scale * x in the same row-pair layout (h1 = rn(scale*x),
- * h2 = rn(scale*x - h1); scale a power of two that puts the largest magnitude of x below 65504 - 2^14 <= max < 2^15 for weights,
+ * h2 = rn(scale*x - h1); scale a power of two that puts the largest magnitude of x below 65504 - 2^13 < max <= 2^14 for weights,
  * a fixed 4 for activations) and three matrix-core products instead of six: a few fp32 round-offs per product instead of one, half
  * the matrix-core work.  Used by the frozen ResNet forward (conv mode 2, dic_resnet_fwd). */
 int dic_split_f16x2_paired(const float* x, long long rows, int K, float scale, uint16_t* h1, uint16_t* h2, void* stream);
+/* ... with the overflow guard: *overflow (device uint32, set to 0 by the caller beforehand) is raised when |scale * x| exceeds 65504
+ * anywhere or x is not finite - the planes then hold inf and every product they enter is NaN.  For activations (the DPT front-end
+ * checks the word once per forward). */
+int dic_split_f16x2_paired_checked(const float* x, long long rows, int K, float scale, uint16_t* h1, uint16_t* h2, uint32_t* overflow,
+                                   void* stream);
 int dic_gemm_bf16x3_paired(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_mid, const uint16_t* a_lo,
                            const uint16_t* b_hi, const uint16_t* b_mid, const uint16_t* b_lo, float* C, long long ldc,
                            const float* bias, void* stream);
@@ -363,6 +397,9 @@ int dic_depth_standardize(float* depth, int B, long long hw, void* stream);
  * forward that ran ahead with zeroed scratch buffers in the running_mean / running_var slots of its layer table (those then
  * hold momentum * batch statistic); keeps the statistics in batch order with several forwards in flight (engine.py). */
 int dic_bn_ema_update(float* running, const float* delta, long long n, float momentum, void* stream);
+/* ... skipped on the device when *skip_if_raised != 0 (the f16x2 overflow guard word of the forward that produced `delta`) */
+int dic_bn_ema_update_guarded(float* running, const float* delta, long long n, float momentum, const uint32_t* skip_if_raised,
+                              void* stream);
 /* out[r,:] = table[idx[r],:] (rows of row_floats floats, % 4 == 0; idx int64 on device): depth cache lookup. */
 int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row_floats, float* out, void* stream);
 
@@ -395,6 +432,11 @@ int dic_debug_force_staged_gemm(int on);
 int dic_conv_persistent_grid(int max_workgroups);
 int dic_profile_begin(void);
 int dic_profile_end(int max_entries, int* keys, double* total_ms, double* total_flops, long long* launches, int* n_out);
+/* the same with the algorithmic HBM bytes of the launches per instantiation (operands read once + output written once; the
+ * on-the-fly operand: raw input + residual read, fp32 copy written): intensity = flops / bytes against the machine balance decides
+ * which roofline bounds the kernel */
+int dic_profile_end_bytes(int max_entries, int* keys, double* total_ms, double* total_flops, double* total_bytes, long long* launches,
+                          int* n_out);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-os.environ.setdefault("DIC_LIB", "experiments")
+# (no import-time change of the environment: the library is chosen by the DIC_LIB the caller exports - a collected but
+#  deselected copy of this file must not redirect the product suite to libdic_experiments.so)
 
 from depth_image_captioning_pub_amd import _lib, native, synthetic as syn      # noqa: E402
 from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr          # noqa: E402
@@ -19,8 +20,11 @@ from oracle import captioning_oracle as orc                                     
 from tests.test_decoder_gpu import _assert_close, _inputs, _to_dev              # noqa: E402
 
 DEV = "cuda:0"
-pytestmark = pytest.mark.skipif(not torch.cuda.is_available() or not os.path.exists(_lib.LIB_EXPERIMENTS_PATH),
-                                reason="needs a GPU and libdic_experiments.so")
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("DIC_LIB") != "experiments" or not torch.cuda.is_available() or
+                                 not os.path.exists(_lib.LIB_EXPERIMENTS_PATH),
+                                 reason="run as `DIC_LIB=experiments python -m pytest scripts/experiments` on a GPU box with "
+                                        "libdic_experiments.so built")]
 
 
 @pytest.fixture(scope="module")

@@ -27,7 +27,7 @@ def split_bf16(x, n):
 
 def split_fp16(x, n):
     m = float(x.abs().max())
-    s = 2.0 ** math.floor(14 - math.log2(m)) if m > 0 else 1.0          # largest element lands in [2^14, 2^15)
+    s = 2.0 ** math.floor(14 - math.log2(m)) if m > 0 else 1.0          # largest element lands in (2^13, 2^14]
     out, r = [], x * s
     for _ in range(n):
         t = r.to(torch.float16).to(torch.float32)

@@ -12,7 +12,68 @@ def test_library_builds_and_exports_header_symbols():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/dic.h but not exported: {missing}"
     lib.dic_version.restype = ctypes.c_int
-    assert lib.dic_version() >= 100
+    # the library, the header it was built from and the Python bindings state ONE version (the struct / argument-list
+    # changes of round 3 went out under the old number)
+    import re
+    header = int(re.search(r"#define\s+DIC_ABI_VERSION\s+(\d+)", open(_lib.HEADER).read()).group(1))
+    assert lib.dic_version() == header == _lib.ABI_VERSION == 200
+
+
+def test_ctypes_mirrors_have_the_size_of_the_library_structs():
+    """A hand-written mirror (ctypes here; cgo / JNI for other adopters) that lags the header would stride a layer table wrongly:
+    wild weight pointers on the device.  dic_struct_bytes lets a binding check before its first call."""
+    from depth_image_captioning_pub_amd import native
+    lib = ctypes.CDLL(build.build())
+    lib.dic_struct_bytes.restype = ctypes.c_size_t
+    for which, mirror in ((0, native.ConvBnLayer), (1, native.DecoderPtrs), (2, native.DecoderPtrs), (3, native.DepthPtrs),
+                          (4, native.DepthPtrs), (5, native.DepthBnState)):
+        assert lib.dic_struct_bytes(which) == ctypes.sizeof(mirror) > 0, (which, mirror.__name__)
+        _lib.check_struct(lib, which, mirror)
+    assert ctypes.sizeof(native.ConvBnLayer) == 72 and lib.dic_struct_bytes(99) == 0
+
+
+def test_loader_refuses_a_library_of_another_abi_version(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 100)
+    try:
+        _lib.load()
+    except _lib.DicError as e:
+        assert "ABI version 200" in str(e)
+    else:
+        raise AssertionError("a version mismatch must raise")
+
+
+def test_ineligible_on_the_fly_convolution_reports_why():
+    """VERDICT r03 engineering item 11: dic_debug_conv1x1_bn returned 1 with an EMPTY dic_last_error() for a shape the launch policy
+    keeps off the on-the-fly-operand kernel (CO = 64).  The decision is taken on the host before any HIP call, so this runs without
+    a GPU (the pointers are never dereferenced)."""
+    lib = ctypes.CDLL(build.build())
+    lib.dic_last_error.restype = ctypes.c_char_p
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    planes = (ctypes.c_void_p * 3)(p, p, p)
+    mt = ctypes.c_int(0)
+    rc = lib.dic_debug_conv1x1_bn(p, p, p, None, 1, None, 200704, 256, planes, 64, p, None, ctypes.byref(mt), p, 1024, None)
+    assert rc == 1
+    msg = lib.dic_last_error().decode()
+    assert "not eligible" in msg and "CO=64" in msg and "nothing was launched" in msg, msg
+
+
+def test_default_resnet_arithmetic_is_the_benchmarked_one_everywhere():
+    """bench.py measured f16x2 while engine / shim / harness defaulted to exact fp32 (2.3x slower): a maintainer
+    following INTEGRATION.md did not get the headline.  One constant now feeds all of them."""
+    import inspect
+    from depth_image_captioning_pub_amd import native
+    from depth_image_captioning_pub_amd.engine import CaptionTrainer
+    from depth_image_captioning_pub_amd.Captioning_models.config import ConfigTrain
+    from depth_image_captioning_pub_amd.Captioning_models.Base_caption_model.base_caption_models import CNNEncoder_Atten
+    import bench
+    assert native.DEFAULT_CONV_MODE == "f16x2"
+    assert ConfigTrain().conv_mode == native.DEFAULT_CONV_MODE
+    assert inspect.signature(native.ResNetRunner.__init__).parameters["conv_mode"].default == native.DEFAULT_CONV_MODE
+    assert inspect.signature(CaptionTrainer.__init__).parameters["conv_mode"].default is None      # None -> DEFAULT_CONV_MODE
+    assert CNNEncoder_Atten(14, layers=(1, 1, 1, 1)).conv_mode == native.DEFAULT_CONV_MODE
+    assert bench.build_parser().get_default("conv_mode") == native.DEFAULT_CONV_MODE
 
 
 def test_loader_fails_loudly_when_library_missing(monkeypatch, tmp_path):

@@ -325,11 +325,19 @@ def test_prefetch_is_ordered_with_eager_forwards(lib):
         out = [tr.train_step(xs[0], depth, caps, lens, drop_mult=drop, **nxt(1)),
                tr.train_step(xs[1], depth, caps, lens, drop_mult=drop),                 # consumes the prefetch
                tr.eval_loss(big, depth6, caps6, lens6),     # eager, larger batch: re-allocates the ResNet workspace
-               tr.train_step(xs[2], depth, caps, lens, drop_mult=drop, **nxt(0)),       # prefetch: stale graphs must go
-               tr.train_step(xs[1], depth, caps, lens, drop_mult=drop),     # NOT the prefetched batch: eager while pending
-               tr.train_step(xs[0], depth, caps, lens, drop_mult=drop, **nxt(2)),       # consumes; prefetches again
-               tr.train_step(xs[2], depth, caps, lens, drop_mult=drop)]
+               tr.train_step(xs[2], depth, caps, lens, drop_mult=drop, **nxt(0))]       # prefetch: stale graphs must go
+        # NOT the announced batch: the pending forward (xs[0]) is DISCARDED on purpose - warning + counter - and the step runs its
+        # own eager forward, ordered behind the side stream (engine._take_prefetched)
+        if overlap:
+            with pytest.warns(RuntimeWarning, match="prefetched ResNet forward"):
+                out.append(tr.train_step(xs[1], depth, caps, lens, drop_mult=drop))
+            assert tr.prefetch_dropped == 1 and not tr.queue
+        else:
+            out.append(tr.train_step(xs[1], depth, caps, lens, drop_mult=drop))
+        out += [tr.train_step(xs[0], depth, caps, lens, drop_mult=drop, **nxt(2)),     # (its prefetch was discarded above: eager); prefetches again
+                tr.train_step(xs[2], depth, caps, lens, drop_mult=drop)]                # consumes
         torch.cuda.synchronize()
+        assert tr.prefetch_dropped == (1 if overlap else 0)
         return [float(x.item()) for x in out], tr.flat.data.clone()
 
     l_o, p_o = run(True)

@@ -79,7 +79,8 @@ def _inputs(B):
     return o
 
 
-@pytest.mark.parametrize("conv_mode,compact", [("f16x2", True), ("bf16x3", True), ("bf16x3", False), ("fp32", True), ("fp32", False)])
+@pytest.mark.parametrize("conv_mode,compact", [("f16x2", True), ("f16x2", False), ("bf16x3", True), ("bf16x3", False), ("fp32", True),
+                                               ("fp32", False)])
 @pytest.mark.parametrize("B", [32, 64])
 def test_full_size_step_vs_oracle(lib, B, conv_mode, compact):
     o = _inputs(B)
@@ -159,7 +160,8 @@ def test_full_size_step_vs_oracle(lib, B, conv_mode, compact):
     torch.cuda.empty_cache()
 
 
-def test_full_size_hard_attention_step_vs_oracle(lib):
+@pytest.mark.parametrize("conv_mode", ["f16x2", "bf16x3"])      # f16x2 = the engine / bench default; bf16x3 = exact operands
+def test_full_size_hard_attention_step_vs_oracle(lib, conv_mode):
     """BASELINE config 4 per rank (depth-hard, batch 32 = 128 / 4 GPUs, seq-len 20, V = 10 000, temp 1.0, 196 cells,
     explicit Gumbel noise [T,B,196] and dropout mask): the same stage-B comparison as the soft step - the oracle gets the HIP
     path's ResNet-152 features and replays its depth-encoder selections; loss (cross-entropy only, depth_train.py:530)
@@ -170,7 +172,7 @@ def test_full_size_hard_attention_step_vs_oracle(lib):
     u = syn.gumbel_uniforms(T, B, seed=223)
     temp = torch.tensor(1.0)
     tr = CaptionTrainer(VOCAB, device=DEV, seed=123, hard=True, decoder_init=o["dec"], depth_init=o["enc"],
-                        depth_state=copy.deepcopy(o["st"]), resnet_init=copy.deepcopy(o["rn"]), conv_mode="bf16x3")
+                        depth_state=copy.deepcopy(o["st"]), resnet_init=copy.deepcopy(o["rn"]), conv_mode=conv_mode)
     tr.keep_outputs = True
     loss = tr.train_step(o["imgs"].to(DEV), o["depth"].to(DEV), o["caps"].to(DEV), o["lens"], drop_mult=o["drop"].to(DEV),
                          gumbel_u=u.to(DEV), temp=1.0, apply_update=False)
@@ -210,7 +212,8 @@ def test_full_size_hard_attention_step_vs_oracle(lib):
     assert abs(loss - float(own[0])) <= 1e-4, (loss, float(own[0]))
 
 
-def test_config1_base_soft_8_images_step_vs_oracle(lib):
+@pytest.mark.parametrize("conv_mode", ["f16x2", "bf16x3"])
+def test_config1_base_soft_8_images_step_vs_oracle(lib, conv_mode):
     """BASELINE config 1 (`base_main.py soft coco` on 8 images; reference base_main.py:23-27 -> base_train.py:24-234): one
     training step of the base-soft captioner - full ResNet-152 in train() mode (batch-statistics BatchNorm over the 8 images) ->
     RNNDecoderWithSoftAttention (ragged caption lengths, explicit dropout mask) -> CE + 0.7 x regulariser -> AdamW over the
@@ -235,7 +238,7 @@ def test_config1_base_soft_8_images_step_vs_oracle(lib):
         p64, _, _ = orc.decoder_forward(d64(dec), feats64, torch.zeros_like(feats64), caps, lens, drop.double())
     undec = orc.rows_undecidable_by_oracle(own[1], p64)
     for compact in (True, False):
-        tr = CaptionTrainer(V, device=DEV, seed=123, decoder_init=dec, resnet_init=copy.deepcopy(rn), conv_mode="bf16x3",
+        tr = CaptionTrainer(V, device=DEV, seed=123, decoder_init=dec, resnet_init=copy.deepcopy(rn), conv_mode=conv_mode,
                             use_depth=False)
         tr.compact_ok = compact
         tr.keep_outputs = True
