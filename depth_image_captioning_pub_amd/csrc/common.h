@@ -100,7 +100,9 @@ constexpr float kF16Max = 65504.0f;        // largest finite fp16: a plane value
 // word otherwise (NaN counts as a violation).  The word is what keeps the failure loud: downstream ReLUs are fmaxf(v, 0), which turn the
 // NaN of an overflowed product into 0.  dic_resnet_fwd* fill their output with NaN when it is set; dic_adamw_step / dic_bn_ema_update
 // skip their update when given the word (include/dic.h).  Rare path: one atomic per offending thread.
-__device__ __forceinline__ void f16x2_raise(unsigned* status) { if (status) atomicOr(status, 1u); }
+// Bits of the word say who raised it: 1 bn_apply_planes, 2 bn_relu_maxpool, 4 producer waves of the on-the-fly operand, 8 BatchNorm
+// statistics not finite, 16 split_f16x2_paired (any non-zero value means "raised").
+__device__ __forceinline__ void f16x2_raise(unsigned* status, unsigned who = 1u) { if (status) atomicOr(status, who); }
 __device__ __forceinline__ bool f16x2_out_of_range(float v, float s) { return !(fabsf(v) * s <= kF16Max); }
 
 // fp32 -> two fp16 planes of s*v (s a power of two chosen by the caller): h1 = rn(s*v), h2 = rn(s*v - h1); |s*v - h1 - h2| <= 2^-22 |s*v|

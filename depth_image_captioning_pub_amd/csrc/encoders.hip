@@ -627,7 +627,7 @@ static int resnet_fwd_impl(const dic_conv_bn_layer* layers, int n_layers, const 
   DIC_REQUIRE(mode >= 0 && mode <= 2, "resnet_fwd: mode must be 0 (exact-fp32 MFMA), 1 (bf16x3 split MFMA) or 2 (f16x2 split MFMA)");
   RnWs ws = rn_carve(workspace, workspace_bytes, pl, mode, &ov);
   DIC_REQUIRE(!ov, "resnet_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
-  DIC_CHECK_HIP(hipMemsetAsync(ws.status, 0, 256, st));      // status word (first bytes of the workspace): clear at the start of every forward
+  DIC_TRY(clear_status(ws.status, st));      // status word (first bytes of the workspace): cleared at the start of every forward
   if (mode >= 1) {
     for (int i = 1; i < n_layers; ++i) {
       DIC_REQUIRE(layers[i].w_hi && layers[i].w_mid, "resnet_fwd: split-operand modes need split weights");

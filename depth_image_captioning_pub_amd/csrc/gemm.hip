@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
     bn.mean[c] = (float)mean;
     bn.invstd[c] = invstd;
     const bool finite = fabs(a) <= 1.7e308 && fabs(b) <= 1.7e308;      // (as bn_finalize_train_kernel: the overflow guard's second line)
-    if (!finite) f16x2_raise(bn.status);
+    if (!finite) f16x2_raise(bn.status, 8u);
     if (bn.running_mean && finite) {
       const double unb = bn.count > 1.0 ? var * bn.count / (bn.count - 1.0) : var;
       bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) split_f16x2_paired_kernel(const float* __
     if (r < rows) v = *reinterpret_cast<const float4*>(x + r * K + k);
     unsigned short a[4], b[4];
     if (f16x2_out_of_range(v.x, scale) | f16x2_out_of_range(v.y, scale) | f16x2_out_of_range(v.z, scale) | f16x2_out_of_range(v.w, scale))
-      f16x2_raise(status);                // overflow guard (common.h)
+      f16x2_raise(status, 16u);           // overflow guard (common.h)
     split2_f16(v.x, scale, a[0], b[0]); split2_f16(v.y, scale, a[1], b[1]);
     split2_f16(v.z, scale, a[2], b[2]); split2_f16(v.w, scale, a[3], b[3]);
     reinterpret_cast<uint2*>(h1)[i] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
         mx = fmaxf(fmaxf(mx, fabsf(v[1][3])), fabsf(v[2][0])); mx = fmaxf(fmaxf(mx, fabsf(v[2][1])), fabsf(v[2][2]));
         mx = fmaxf(fmaxf(mx, fabsf(v[2][3])), fabsf(v[3][0])); mx = fmaxf(fmaxf(mx, fabsf(v[3][1])), fabsf(v[3][2]));
         mx = fmaxf(mx, fabsf(v[3][3]));
-        if (mx > kF16Max / kF16ActScale) f16x2_raise(p.status);
+        if (mx > kF16Max / kF16ActScale) f16x2_raise(p.status, 4u);
       }
       if (__builtin_amdgcn_readfirstlane(S.flg) & 32u) {        // last M tile of a ragged matrix: rows past the end are zero
         asm volatile("" ::: "memory");                           // (keeps this a branch: 16 selects per slot otherwise)

@@ -40,6 +40,7 @@ int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn,
                     unsigned* status = nullptr)                  /* f16x2 planes: overflow guard word */;
 // y[0..n) = NaN if *status != 0 (the loud end of the f16x2 overflow guard: one small launch, returns at once otherwise)
 int poison_if_raised(float* y, long long n, const unsigned* status, hipStream_t st);
+int clear_status(unsigned* status, hipStream_t st);      // status[0..63] = 0 (a kernel: see nn_kernels.hip for why not a memset)
 // adaptive average pooling of an NHWC map to OUTxOUT (AdaptiveAvgPool2d(14): exact 2x2 replication for 7x7)
 // with optional fused BN+ReLU on load
 int adaptive_avgpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int out, float* y,

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_train_kernel(const float* __
     // an inf / NaN in the convolution output (an overflowed f16x2 plane upstream, a non-finite input image) shows here as non-finite
     // sums: raise the guard word and keep the running statistics of this channel as they were
     const bool finite = fabs(a) <= 1.7e308 && fabs(b) <= 1.7e308;
-    if (!finite) f16x2_raise(status);
+    if (!finite) f16x2_raise(status, 8u);
     if (rmean && finite) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
       rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) bn_finalize_from_slices_kernel(const doub
   out.mean[c] = (float)mean;
   out.invstd[c] = invstd;
   const bool finite = fabs(a) <= 1.7e308 && fabs(b) <= 1.7e308;      // (see bn_finalize_train_kernel)
-  if (!finite) f16x2_raise(status);
+  if (!finite) f16x2_raise(status, 8u);
   if (rmean && finite) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     rmean[c] = (1.f - kBnMomentum) * rmean[c] + kBnMomentum * (float)mean;
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
       unsigned short h[4], m[4], l[4];
       if (!lo) {    // f16x2 format: two fp16 planes of kF16ActScale * v
         if (f16x2_out_of_range(best.x, kF16ActScale) | f16x2_out_of_range(best.y, kF16ActScale) | f16x2_out_of_range(best.z, kF16ActScale) |
-            f16x2_out_of_range(best.w, kF16ActScale)) f16x2_raise(status);
+            f16x2_out_of_range(best.w, kF16ActScale)) f16x2_raise(status, 2u);
         split2_f16(best.x, kF16ActScale, h[0], m[0]); split2_f16(best.y, kF16ActScale, h[1], m[1]);
         split2_f16(best.z, kF16ActScale, h[2], m[2]); split2_f16(best.w, kF16ActScale, h[3], m[3]);
       } else {
@@ -395,6 +395,16 @@ __global__ void __launch_bounds__(256) poison_if_raised_kernel(float* __restrict
   if (*status == 0u) return;
   const float nan = __uint_as_float(0x7fc00000u);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = nan;
+}
+// Clears the guard word.  A kernel, not hipMemsetAsync: the forward is captured into hipGraphs that several streams (and, with ranks
+// sharing a GPU, several processes) replay concurrently, and a captured 256-byte memset node was observed to leave bit patterns of
+// other data in the word on replay (gpurun_out/r04_dbg.log: slot words 0x421ffc00 after the second and third slot's replays, zero with
+// DIC_RESNET_GRAPH=0) - kernel nodes replay exactly what was captured.
+__global__ void clear_status_kernel(unsigned* __restrict__ status) { status[threadIdx.x] = 0u; }
+int clear_status(unsigned* status, hipStream_t st) {
+  hipLaunchKernelGGL(clear_status_kernel, dim3(1), dim3(64), 0, st, status);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
 }
 int poison_if_raised(float* y, long long n, const unsigned* status, hipStream_t st) {
   hipLaunchKernelGGL(poison_if_raised_kernel, dim3(64), dim3(256), 0, st, y, n, status);

@@ -366,6 +366,12 @@ class CaptionTrainer:
         """Copy the word to the host ring (asynchronous) after the update of this step has been enqueued."""
         if self.conv_mode != "f16x2":
             return
+        if os.environ.get("DIC_DEBUG_GUARD"):
+            torch.cuda.synchronize()
+            print(f"[guard rank {self.rank}] step {self.step_count}: word {int(self.guard.item()) & 0xffffffff:#x}; slot words "
+                  f"{[hex(int(sl.runner.status_word().item()) & 0xffffffff) for sl in self.slots if sl.runner.workspace is not None]}; own "
+                  f"{hex(int(self.resnet.status_word().item()) & 0xffffffff) if self.resnet.workspace is not None else None}; ws "
+                  f"{[(sl.runner.workspace.data_ptr(), sl.runner.workspace.numel(), list(sl.graphs)) for sl in self.slots if sl.runner.workspace is not None]}", flush=True)
         if len(self._guard_pending) >= self._guard_host.numel():      # ring full (16 steps un-polled): settle the oldest first
             self._guard_poll(block=True)
         i = self._guard_slot
@@ -381,10 +387,11 @@ class CaptionTrainer:
             i, ev, step = self._guard_pending.pop(0)
             ev.synchronize()
             if int(self._guard_host[i]) != 0:
-                bad.append(step)
+                bad.append((step, int(self._guard_host[i])))
         if bad:
             self.step_count -= len(bad)        # the device skipped those updates: Adam's bias correction must not count them
-            raise DicError(f"f16x2 overflow guard: the ResNet-152 forward of optimiser step(s) {bad} produced an activation beyond the "
+            raise DicError(f"f16x2 overflow guard: the ResNet-152 forward of optimiser step(s) {[b[0] for b in bad]} (guard words "
+                           f"{[hex(b[1]) for b in bad]}: bits in csrc/common.h) produced an activation beyond the "
                            "fp16 range of the operand planes (|x| > 16376) or a non-finite value; its features were NaN and AdamW was "
                            "skipped on the device for those steps, so parameters, Adam moments and BatchNorm running statistics are "
                            "as they were before them.  Re-create the trainer with conv_mode='bf16x3' (exact operands, no range limit)")
