@@ -95,7 +95,8 @@ def profile_step(trainer, args_step):
                                5: (f"gemm_bf3_persist_ws_kernel<{kind}>", f"gemm_bf3_persist_ws_kernel<{a}, 0, 3, {int(f16)}>"),
                                6: ("conv3x3_bf3_halo_kernel", f"conv3x3_bf3_halo_kernel<0, {int(f16)}>"),
                                7: (f"gemm_bf3_persist_ws256_kernel<{kind}>", f"gemm_bf3_persist_ws256_kernel<{a}"),
-                               8: (f"gemm_bf3_persist_kernel<{kind}>", f"gemm_bf3_persist_kernel<{a}")}[tcode]
+                               8: (f"gemm_bf3_persist_kernel<{kind}>", f"gemm_bf3_persist_kernel<{a}"),
+                               9: ("conv1x1_astat_bn_kernel (A-stationary conv3, BatchNorm-apply fused)", "conv1x1_astat_bn_kernel<")}[tcode]
                 rows.append({"kernel": name + (" [f16x2]" if f16 else ""), "rocprof_name": rname, "launches": int(cnt[i]), "total_ms": ms[i],
                              "flops": fl[i], "bytes": by[i], "peak": peak})
                 continue

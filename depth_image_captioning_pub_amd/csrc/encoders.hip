@@ -129,8 +129,8 @@ struct RnPlan {
 
 static void rn_track(RnPlan& pl, const ConvDesc& d) {
   pl.max_act = std::max(pl.max_act, (size_t)d.M() * d.CO);
-  pl.max_partial = std::max(pl.max_partial, (size_t)(d.M() / 64 + 2) * 2 * d.CO);
-  pl.max_red = std::max(pl.max_red, bn_finalize_ws_doubles(d.M() / 64 + 2, d.CO));
+  pl.max_partial = std::max(pl.max_partial, (size_t)(d.M() / 32 + 4) * 2 * d.CO);      // (the A-stationary conv3 kernel: partials per 32 rows)
+  pl.max_red = std::max(pl.max_red, bn_finalize_ws_doubles(d.M() / 32 + 4, d.CO));
 }
 
 static RnPlan resnet_plan(int B, int H, int W, const int* blocks) {
@@ -267,6 +267,20 @@ static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* 
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
+// conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: relu(bn2(raw2)) is formed once per 64-row block inside the kernel (no
+// bn_apply_planes pass, no planes).  Returns 1 when the shape is not that kernel's.
+static int conv_bn_bf3_astat(const float* raw, const BnBuf& in_bn, const ConvDesc& d, const dic_conv_bn_layer& L, float* y, const RnWs& ws,
+                             int train_bn, hipStream_t st, const BnBuf& bn) {
+  if (!(d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) || !conv1x1_astat_eligible(d.M(), d.C, d.CO)) return 1;
+  int mtiles = 0;
+  const unsigned short* wp[3] = {L.w_hi, L.w_mid, nullptr};
+  DIC_TRY(conv1x1_astat_bn(raw, in_bn.scale, in_bn.shift, 1, d.M(), d.C, wp, d.CO, y, train_bn ? ws.partial : nullptr, &mtiles, st,
+                           1.0f / (kF16ActScale * L.w_scale), ws.status));
+  if (train_bn)
+    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, ws.red, st, ws.status);
+  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+}
+
 // which BatchNorm-apply passes are folded into the consuming 1x1 convolution (codes 100..103 of dic_debug_force_staged_gemm):
 // bit 0 = the block output (relu(bn3(conv3) + identity), consumed by the next block's conv1), bit 1 = conv2's output (consumed by conv3)
 static int g_fuse_bn_operand_switch = -1;      // -1 (code 104, default): by operand format - both for bf16x3; block outputs only for f16x2, where the
@@ -346,8 +360,10 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
         DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st, &ws.bn_ds, fmt));
       }
       {
-        int rc = (g_fuse_bn_operand & 2) ? conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3, fmt)
-                                         : 1;
+        // (an explicit folding switch 100..103 keeps the routes it names; the A-stationary kernel belongs to the default, 104)
+        int rc = (fmt && g_fuse_bn_operand_switch < 0) ? conv_bn_bf3_astat(R2, ws.bn2, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3) : 1;
+        if (rc == 1 && (g_fuse_bn_operand & 2))
+          rc = conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3, fmt);
         if (rc == 1) {
           DIC_BN_APPLY_PLANES(R2, nullptr, nullptr, nullptr, P2, c2.d.M(), c2.d.CO, ws.bn2, 1, st, nullptr, guard);
           rc = conv_bn_bf3(P2, c3.d, layers[c3.layer], R3, ws, train_bn, st, &ws.bn3, fmt);

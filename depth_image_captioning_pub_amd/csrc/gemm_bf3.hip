@@ -545,7 +545,11 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       const int t = it_tile(itl), tm = t / p.ntiles, tn = t - tm * p.ntiles;
       const int gr = tm * BM + prow0;
       lrow0 = (unsigned)gr * ldb + (unsigned)kq * 16u;
-      lflg = ((tn == 0 && p.a_out != nullptr) ? 16u : 0u) | ((tm * BM + BM > p.M) ? 32u : 0u);
+      // the fp32 copy of the input (a_out) is written once per row block: by the N tile that "owns" this producer wave's 32 rows - the
+      // four waves are dealt over the first min(ntiles, 4) N tiles of the row block, so that sibling tiles carry the same store load and
+      // stay in step (they read the same input rows: in step, the second read hits L2; until round 4 the tn == 0 tile stored everything)
+      const int owner = ((pt >> 6) * min(p.ntiles, 4)) >> 2;
+      lflg = ((tn == owner && p.a_out != nullptr) ? 16u : 0u) | ((tm * BM + BM > p.M) ? 32u : 0u);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         lflg |= (gr + 8 * i < p.M) ? (1u << i) : 0u;
@@ -1336,11 +1340,213 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
 #undef DIC_PIPE_MFMA
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// "A-stationary" 1x1 convolution with a short contraction and the BatchNorm-apply of its input fused in:
+//     y[M][N] = relu(raw[M][K] * scale[K] + shift[K]) . W[N][K]^T ,   K = 32 * KT <= 256, N % 128 == 0     (f16x2 operand format)
+// - the bottleneck expansions conv3 of ResNet layers 2 and 3 (K = 128 / 256, N = 4 K; 44 of the 50 conv3 launches).  Until round 4 they
+// cost a bn_apply_planes pass (read raw conv2 output, write two fp16 planes) plus a plane kernel that streams A and B tiles through a ring
+// for only 4 / 8 K tiles per output tile (28 us at layer 3 for 11 us of matrix work: prologue / drain per tile and the 51-MB output write).
+// Here a workgroup owns a 64-row block of the input for ALL N: the producer waves read its raw fp32 rows ONCE (64 x K floats), normalise,
+// rectify, split and leave the two fp16 planes resident in LDS (64 KB at K = 256) - no pass, no planes in HBM, no re-transform per N
+// tile (what made the on-the-fly operand of gemm_bf3_persist_ws_kernel a loss for conv3: 8 N tiles = 8 transforms) - and only the
+// weights stream (LDS-DMA ring, 3 stages of two K tiles = 32 KB; the whole W is 1 MB and L2-resident).  One long loop of
+// N/128 x K/64 stage steps per workgroup, 24 MFMAs per computing wave between barriers as in the persistent kernels, an output tile
+// stored every K/64 steps while the ring keeps running.  Computing waves: 2 x 2, 32 rows x 64 columns each.
+// Summation order per output element = the plane kernels' (K tiles in order, k-steps in order, products h2*h1', h1*h2', h1*h1'), and the
+// operand values are bn_apply_planes' (fma, max, split2_f16): bit-identical to the plane route.  BatchNorm partial sums per 32-row wave
+// tile: [2 * ceil(M / 64)][2][N].  LDS: 2 * 64 * K * 2 B + 96 KB = 160 KB at K = 256.
+template <int KT>
+__global__ void __launch_bounds__(512) conv1x1_astat_bn_kernel(const Bf3Params p) {
+  constexpr int BM = 64, BN = 128, NPL = 2, NSTB = 3, K = KT * 32;
+  constexpr int APLANE = BM * K;                      // elements per plane of the resident A image: [KT][64 rows][32]
+  constexpr int BTILE = NPL * BN * BK3;               // one K tile of B as the loader lays it out: [plane][128][32] (16 KB)
+  constexpr int BSTAGE = 2 * BTILE;                   // a ring stage = two K tiles
+  constexpr int SPN = KT / 2;                         // stage steps per 128-column N tile
+  constexpr int NB = 2 * 2 * NPL;                     // DMA instructions per producer wave and stage
+  __shared__ __align__(1024) unsigned short smem[NPL * APLANE + NSTB * BSTAGE];
+  unsigned short* const bring = smem + NPL * APLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tm = xcd_remap(blockIdx.x, gridDim.x);
+  const int NT = p.N / BN, S = NT * SPN;              // stage steps of this workgroup
+
+  if (wave >= 4) {
+    // ================= producer waves
+    const int pw = wave - 4;
+    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
+    int sb = 0;
+    auto issue_b = [&](unsigned short* stage) {
+      const int tn = sb / SPN, kp = sb - tn * SPN;
+      if (kp == 0) lbld.init(p.B, tn * BN, p.N, p.K);
+      lbld.issue(kp * 64, stage);
+      lbld.issue(kp * 64 + 32, stage + BTILE);
+      ++sb;
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < NSTB; ++s0)
+      if (s0 < S) issue_b(bring + s0 * BSTAGE);
+    // ---- the A block, once: thread (r8, kq) of producer wave pw takes channels 4*kq .. 4*kq+3 of every K tile for rows pw*16 + r8 and
+    // pw*16 + r8 + 8 (a wave instruction reads 8 rows x 128 B: whole cache lines)
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const int r8 = lane >> 3, kq = lane & 7;
+    f32x4_ xa[KT][2], sc[KT], sh[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gr = min(tm * BM + pw * 16 + r8 + 8 * i, p.M - 1);
+        xa[kt][i] = *reinterpret_cast<const f32x4_*>(p.a_raw + (size_t)gr * p.a_ld + kt * 32 + kq * 4);
+      }
+      sc[kt] = *reinterpret_cast<const f32x4_*>(p.a_scale + kt * 32 + kq * 4);
+      sh[kt] = *reinterpret_cast<const f32x4_*>(p.a_shift + kt * 32 + kq * 4);
+    }
+    const float floor_ = p.a_relu ? 0.f : -__builtin_inff();
+    const unsigned abase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+    bool bad = false;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rl = pw * 16 + r8 + 8 * i;
+        const bool in = tm * BM + rl < p.M;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float a = fmaf(xa[kt][i][u], sc[kt][u], sh[kt][u]);             // = bn_apply_planes: fma, then the ReLU
+          v[u] = fmaxf(a, floor_);
+          bad |= (a != a) | f16x2_out_of_range(v[u], kF16ActScale);             // overflow guard (common.h); a NaN would not survive the fmaxf
+          v[u] = in ? v[u] : 0.f;                                               // rows past the end of the matrix: exact zeros
+        }
+        typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        u32x2_ q1, q2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                                           // = split2_f16(v, kF16ActScale)
+          const f32x2_ xx = f32x2_{v[2 * u], v[2 * u + 1]} * kF16ActScale;
+          const f16x2_ h1 = __builtin_convertvector(xx, f16x2_);
+          const f32x2_ r1 = xx - __builtin_convertvector(h1, f32x2_);
+          q1[u] = __builtin_bit_cast(unsigned, h1); q2[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_));
+        }
+        const unsigned dst = abase + (unsigned)(kt * (BM * 64) + rl * 64) + ((((unsigned)kq >> 1) ^ (((unsigned)rl >> 2) & 3u)) << 4) + ((unsigned)kq & 1u) * 8u;
+        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(q1) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(q2), "i"(APLANE * 2) : "memory");
+      }
+    if (bad) f16x2_raise(p.status, 4u);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               // A image written, ring stages 0..2 landed
+    __builtin_amdgcn_s_barrier();
+    for (int g = 0; g < S; ++g) {
+      // stage g+1 must have landed before the computing waves read it (after this barrier); stage g+2 may stay in flight
+      if (g + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                             // ... and they are done with stage g % NSTB
+      if (g + NSTB < S) issue_b(bring + (g % NSTB) * BSTAGE);
+    }
+    return;
+  }
+
+  // ================= computing waves
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
+  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
+  const unsigned offA = sbase0 + (unsigned)((wm * 32 + i31) * 64);
+  const unsigned offB = sbase0 + (unsigned)(NPL * APLANE * 2) + (unsigned)((wn * 64 + i31) * 64);
+  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  u32x4 fa[2][2], fb[2][2][2];                      // [buffer][plane], [buffer][column tile][plane]
+  // fragments of k-step Q_ (0..3) of the ring stage at byte offset STB_, A K tile AKT_, into register buffer BUF_
+#define DIC_AS_READ(BUF_, AKT_, Q_, STB_)                                                                                         \
+  _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                                              \
+      bf3_lds_read(fa[BUF_][pl], offA + (unsigned)(pl * APLANE * 2) + (unsigned)((AKT_) * (BM * 64)) + pos[(Q_) & 1]);            \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                \
+      bf3_lds_read(fb[BUF_][j][pl], offB + (STB_) + (unsigned)((((Q_) >> 1) * BTILE + pl * BN * BK3) * 2 + j * 32 * 64) + pos[(Q_) & 1]);
+#define DIC_AS_PIN(BUF_)                                                                                                          \
+  _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) { asm volatile("" : "+v"(fa[BUF_][pl]));                                     \
+    asm volatile("" : "+v"(fb[BUF_][0][pl])); asm volatile("" : "+v"(fb[BUF_][1][pl])); }
+#define DIC_AS_MFMA(BUF_, PA_, PB_)                                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] = bf3_mfma<1>(fa[BUF_][PA_], fb[BUF_][j][PB_], acc[j]);
+#define DIC_AS_MFMA_ALL(BUF_) DIC_AS_MFMA(BUF_, 1, 0) DIC_AS_MFMA(BUF_, 0, 1) DIC_AS_MFMA(BUF_, 0, 0)
+  __builtin_amdgcn_s_barrier();                      // the A image and ring stage 0 are in LDS
+  DIC_AS_READ(0, 0, 0, 0u)
+  int kp = 0, tn = 0, st = 0;
+  for (int s = 0; s < S; ++s) {
+    const int stn = st == NSTB - 1 ? 0 : st + 1;
+    const unsigned stb = (unsigned)(st * BSTAGE * 2), stbn = (unsigned)(stn * BSTAGE * 2);
+    const int akt = kp * 2, aktn = kp == SPN - 1 ? 0 : akt + 2;
+    DIC_AS_READ(1, akt, 1, stb)
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    DIC_AS_PIN(0)
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_AS_MFMA_ALL(0)
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_AS_READ(0, akt + 1, 2, stb)
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    DIC_AS_PIN(1)
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_AS_MFMA_ALL(1)
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_AS_READ(1, akt + 1, 3, stb)
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    DIC_AS_PIN(0)
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_AS_MFMA_ALL(0)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this stage is in registers
+    DIC_AS_PIN(1)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    DIC_AS_MFMA(1, 1, 0)
+    if (s + 1 < S) { DIC_AS_READ(0, aktn, 0, stbn) }
+    DIC_AS_MFMA(1, 0, 1) DIC_AS_MFMA(1, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    st = stn;
+    if (++kp < SPN) continue;
+    kp = 0;
+    // ---- N tile tn is complete: unscale, store, BatchNorm partial sums of this wave's 32 rows (rows past M hold exact zeros)
+    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 32 + 4 * h;
+    const bool full = (tm + 1) * BM <= p.M;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[j] *= p.ep.alpha;
+      float* col = p.ep.C + (long long)m0 * p.ep.ldc + n0 + j * 32;
+      float cs = 0.f, cs2 = 0.f;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[j][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (m0 + (r & 3) + 8 * (r >> 2) < p.M) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[j][r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { cs += acc[j][r]; cs2 += acc[j][r] * acc[j][r]; acc[j][r] = 0.f; }
+      if (p.ep.stats) {
+        const float a = cs + __shfl_xor(cs, 32, 64), b = cs2 + __shfl_xor(cs2, 32, 64);
+        if (lane < 32) {
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 0) * p.N + n0 + j * 32] = a;
+          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 1) * p.N + n0 + j * 32] = b;
+        }
+      }
+    }
+    ++tn;
+  }
+#undef DIC_AS_READ
+#undef DIC_AS_PIN
+#undef DIC_AS_MFMA
+#undef DIC_AS_MFMA_ALL
+}
+
 }  // namespace dic
 
 namespace dic {
 
 static int g_last_mtiles = 0;   // M tiles of the most recent launch (row count of the BN partial-sum table)
+void conv1x1_astat_switch(int on);
 // Kernel-selection switches (dic_debug_force_staged_gemm, include/dic.h).  The product library keeps the ones its tests use to
 // compare kernels that the policy below really selects (tile forcing 11 / 21 / 24 / 20, persistent policy 70 / 73 / 79, halo
 // 74 / 75 / 78); the ablations and the parked kernels exist only in the experiments build (-DDIC_EXPERIMENTS).
@@ -1392,6 +1598,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 20 || code == 11 || code == 21 || code == 24) { g_bf3_force = code == 20 ? 0 : code; return 0; }
   if (code == 90 || code == 91) { g_bf3_remainder_split = code - 90; return 0; }      // remainder-round K split of the persistent kernels off / on (default)
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
+  if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never / by shape (default)
 #ifdef DIC_EXPERIMENTS
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
@@ -1644,6 +1851,38 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       DIC_TRY(gemm_launch_tail_fixup(g, tail_tiles, st));
     }
   }
+  return DIC_OK;
+}
+
+// conv3-style 1x1 convolution on the A-stationary kernel (conv1x1_astat_bn_kernel): y_raw[M][CO] = relu(raw[M][C] * scale + shift) . W^T,
+// f16x2 weights planes (scale in out_scale = 1 / (kF16ActScale * w_scale)); BatchNorm partials per 32-row wave tile: *mtiles_out rows
+static int g_astat = 1;                  // codes 110 / 111: off / on (default)
+void conv1x1_astat_switch(int on) { g_astat = on; }
+bool conv1x1_astat_eligible(int M, int C, int CO) {
+  return g_astat != 0 && (C == 128 || C == 256) && CO % 128 == 0 && CO >= 128 && M >= 64 && (long long)(CO + 1) * C * 2 < (1ll << 31);
+}
+int conv1x1_astat_bn(const float* raw, const float* scale, const float* shift, int relu, int M, int C, const unsigned short* const w_planes[3],
+                     int CO, float* y, float* bn_partial, int* mtiles_out, hipStream_t st, float out_scale, unsigned* status) {
+  DIC_REQUIRE(raw && scale && shift && y && w_planes && w_planes[0] && w_planes[1], "conv1x1_astat_bn: null pointer");
+  if (!conv1x1_astat_eligible(M, C, CO)) return 1;
+  Bf3Params p{};
+  p.M = M; p.N = CO; p.K = C;
+  p.B.p[0] = w_planes[0]; p.B.p[1] = w_planes[1]; p.B.p[2] = nullptr;
+  p.B.kind = OPK_ROWK; p.B.ld = C; p.B.paired = 1;
+  p.a_raw = raw; p.a_scale = scale; p.a_shift = shift; p.a_ld = C; p.a_relu = relu; p.status = status;
+  p.ep = ep_store(y, CO, nullptr, ACT_NONE);
+  p.ep.stats = bn_partial;
+  p.ep.alpha = out_scale;
+  p.fmt = 1;
+  const int mt = ceil_div(M, 64);
+  p.mtiles = mt; p.ntiles = CO / 128;
+  gemm_profile_mark_begin(st, 2.0 * M * CO * (double)C, 3000 + OPK_ROWK_BN * 10 + 9,
+                          4.0 * ((double)M * C + (double)CO * C + (double)M * CO));
+  if (C == 256) hipLaunchKernelGGL(conv1x1_astat_bn_kernel<8>, dim3(mt), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(conv1x1_astat_bn_kernel<4>, dim3(mt), dim3(512), 0, st, p);
+  DIC_LAUNCH_CHECK();
+  gemm_profile_mark_end(st);
+  if (mtiles_out) *mtiles_out = 2 * mt;
   return DIC_OK;
 }
 

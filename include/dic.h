@@ -418,6 +418,9 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   100..104     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
  *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both / by operand
  *                format (default: both in mode 1, block outputs only in mode 2)
+ *   110 111      mode 2: conv3 of ResNet layers 2 and 3 (K = 128 / 256) on the A-stationary kernel - the 64-row input block is
+ *                normalised / rectified / split once inside the kernel and stays in LDS for all output columns - never / by shape
+ *                (default; an explicit 100..103 keeps the routes it names)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
  * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes

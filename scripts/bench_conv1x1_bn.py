@@ -81,6 +81,14 @@ for name, M, Cin, CO in (("layer2 conv1", B * 784, 512, 128), ("layer2 conv3", B
         return f
 
     t0 = timeit(plane_route)
+    if a.fmt == 1 and Cin in (128, 256):        # conv3 shapes: the A-stationary kernel (raw input, BatchNorm-apply fused, no planes)
+        part2 = torch.zeros((M // 32 + 4) * 2 * CO, device=DEV)
+
+        def astat():
+            rc = lib.dic_debug_conv1x1_astat(ptr(raw), ptr(scale), ptr(shift), 1, M, Cin, planes(wp), CO, ptr(y), ptr(part2), C.byref(mt), osc,
+                                             None, stream_ptr())
+            assert rc == 0, rc
+        print(f"{name:13s} M={M} {Cin}->{CO}: A-stationary kernel {timeit(astat):7.1f} us")
     if fused(False, False)() == 1:
         print(f"{name:13s} M={M} {Cin}->{CO}: planes {t0:7.1f} us; not on the persistent kernel")
         continue

@@ -179,7 +179,7 @@ def test_training_loop_with_dpt_front_end_and_depth_cache(lib, tmp_path):
     hist = depth_train.train_Cdepth_soft(0, "synthetic", config=Tiny(), stats=stats)
     # 2 epochs x 2 training iterations + 1 validation batch per epoch: every image is predicted once (epoch 0) and read from
     # its cache afterwards - the validation set through its own cache (the reference's depth_dic_val, depth_train.py:258-275)
-    assert stats == {"prefetch_dropped": 0, "dpt_forwards": 2, "cache_hits": 2, "cache_entries": 4,
+    assert stats == {"conv_mode": "f16x2", "prefetch_dropped": 0, "dpt_forwards": 2, "cache_hits": 2, "cache_entries": 4,
                      "val_dpt_forwards": 1, "val_cache_hits": 1, "val_cache_entries": 2}
     assert len(hist) == 2 and all(np.isfinite(v) for pair in hist for v in pair)
 
