@@ -106,12 +106,14 @@ int dic_debug_conv1x1_bn_fmt(const float* raw, const float* scale, const float* 
   return conv1x1_fwd_bf3_bn(raw, scale, shift, res, relu, act_out, M, C, w_planes, CO, y, bn_partial, mtiles_out, tail_ws, tail_ws_slabs,
                             (hipStream_t)stream, nullptr, nullptr, fmt, out_scale);
 }
+#ifdef DIC_EXPERIMENTS
 /* development aid (not in dic.h): the A-stationary conv3 kernel alone (conv1x1_astat_bn, gemm_bf3.hip): y = relu(raw * scale + shift) . W^T
  * with W as f16x2 planes scaled by 1 / (4 * out_scale); bn_partial: (2 * ceil(M / 64)) x 2 x CO floats; returns 1 for shapes it does not take */
 int dic_debug_conv1x1_astat(const float* raw, const float* scale, const float* shift, int relu, int M, int C, const uint16_t* const w_planes[3],
                             int CO, float* y, float* bn_partial, int* mtiles_out, float out_scale, uint32_t* status, void* stream) {
   return conv1x1_astat_bn(raw, scale, shift, relu, M, C, w_planes, CO, y, bn_partial, mtiles_out, (hipStream_t)stream, out_scale, status);
 }
+#endif
 int dic_conv_persistent_grid(int max_workgroups) {
   DIC_REQUIRE(gemm_bf3_set_persist_grid(max_workgroups) == 0, "dic_conv_persistent_grid: 1 <= max_workgroups <= 1024");
   return DIC_OK;

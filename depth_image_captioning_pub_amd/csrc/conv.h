@@ -38,12 +38,12 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
                        int* bn_fused = nullptr, int fmt = 0, float out_scale = 1.0f,
                        unsigned* status = nullptr /* f16x2: overflow guard word (common.h) */);
 bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs);
-// The same operation for SHORT contractions (C = 128 / 256, f16x2 only: ResNet conv3 of layers 2 and 3) on the A-stationary kernel: the
-// 64-row input block is normalised / rectified / split once and stays in LDS for all output columns.  Returns 1 (nothing launched) for
-// other shapes.  BatchNorm partials per 32-row wave tile: *mtiles_out = 2 * ceil(M / 64) rows of [2][CO].
+// (parked, experiments build: the same operation for SHORT contractions on the A-stationary kernel - csrc/experiments/conv1x1_astat.inc)
+#ifdef DIC_EXPERIMENTS
 bool conv1x1_astat_eligible(int M, int C, int CO);
 int conv1x1_astat_bn(const float* raw, const float* scale, const float* shift, int relu, int M, int C, const unsigned short* const w_planes[3],
                      int CO, float* y, float* bn_partial, int* mtiles_out, hipStream_t st, float out_scale, unsigned* status = nullptr);
+#endif
 constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a larger tail region: every CU can take a remainder piece
 // bn_fuse: when the launch is tail-split, finalize the train-mode BatchNorm inside the fix-up launch (*bn_fused = 1)
 // data gradient of a stride-1 convolution through the same kernel: dy planes [B,OH,OW,CO], flipped weights

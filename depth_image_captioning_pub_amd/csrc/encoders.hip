@@ -267,6 +267,7 @@ static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* 
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
 
+#ifdef DIC_EXPERIMENTS
 // conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: relu(bn2(raw2)) is formed once per 64-row block inside the kernel (no
 // bn_apply_planes pass, no planes).  Returns 1 when the shape is not that kernel's.
 static int conv_bn_bf3_astat(const float* raw, const BnBuf& in_bn, const ConvDesc& d, const dic_conv_bn_layer& L, float* y, const RnWs& ws,
@@ -280,6 +281,7 @@ static int conv_bn_bf3_astat(const float* raw, const BnBuf& in_bn, const ConvDes
     return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, ws.red, st, ws.status);
   return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
 }
+#endif
 
 // which BatchNorm-apply passes are folded into the consuming 1x1 convolution (codes 100..103 of dic_debug_force_staged_gemm):
 // bit 0 = the block output (relu(bn3(conv3) + identity), consumed by the next block's conv1), bit 1 = conv2's output (consumed by conv3)
@@ -360,8 +362,10 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
         DIC_TRY(conv_bn_bf3(Xp, ds.d, layers[ds.layer], Cf, ws, train_bn, st, &ws.bn_ds, fmt));
       }
       {
-        // (an explicit folding switch 100..103 keeps the routes it names; the A-stationary kernel belongs to the default, 104)
-        int rc = (fmt && g_fuse_bn_operand_switch < 0) ? conv_bn_bf3_astat(R2, ws.bn2, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3) : 1;
+        int rc = 1;
+#ifdef DIC_EXPERIMENTS      // parked: the A-stationary conv3 kernel (codes 110 / 111; an explicit folding switch 100..103 keeps the routes it names)
+        if (fmt && g_fuse_bn_operand_switch < 0) rc = conv_bn_bf3_astat(R2, ws.bn2, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3);
+#endif
         if (rc == 1 && (g_fuse_bn_operand & 2))
           rc = conv_bn_bf3_fused(R2, ws.bn2, nullptr, nullptr, c3.d, layers[c3.layer], R3, ws, train_bn, st, ws.bn3, fmt);
         if (rc == 1) {

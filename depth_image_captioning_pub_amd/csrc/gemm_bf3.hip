@@ -222,14 +222,22 @@ struct Bf3Loader {
 template <int BR, int NPL = 3>      // NPL: planes of the operand format
 struct Bf3BufLoader {
   static constexpr int NI = BR / 64;
-  __amdgpu_buffer_rsrc_t rs[3];
+  // The buffer descriptor is REBUILT at every issue from scalars that pass through readfirstlane: inside the persistent kernels' work
+  // loops hipcc cannot prove a descriptor kept in a struct across iterations wave-uniform (anything that met threadIdx-derived
+  // control flow counts as divergent), parks it in vector registers and wraps every DMA in a "waterfall" loop - four readfirstlanes,
+  // two 64-bit compares, saveexec, the load, a branch (guide T20).  The on-the-fly-operand kernel had 45 of them (r04: 141
+  // v_readfirstlane in its listing), ~60 instructions per K tile on the producer waves, i.e. on the SIMDs the computing waves use.
+  // A readfirstlane of a value that is already scalar costs nothing.
+  const unsigned short* bp[3];
+  int nbytes;
   unsigned voff[NI];
   int kstep;                  // bytes per K tile
   __device__ __forceinline__ void init(const Bf3Operand& op, int r0, int R, int) {
     const int kb = (int)(op.ld / 32);
     const long long bytes = op.paired ? (long long)((R + 1) / 2) * kb * 128 : (long long)R * op.ld * 2;
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) rs[pl] = __builtin_amdgcn_make_buffer_rsrc((void*)op.p[pl], 0, (int)bytes, 0x00020000);
+    for (int pl = 0; pl < NPL; ++pl) bp[pl] = op.p[pl];
+    nbytes = (int)bytes;
     kstep = op.paired ? 128 : 64;
     const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3;
 #pragma unroll
@@ -242,14 +250,19 @@ struct Bf3BufLoader {
   }
   __device__ __forceinline__ void issue_plain(int k0, unsigned short* img) const {
     const int w = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
-    const int soff = (k0 >> 5) * kstep;
+    const int soff = __builtin_amdgcn_readfirstlane((k0 >> 5) * kstep);
+    const int nb = __builtin_amdgcn_readfirstlane(nbytes);
 #pragma unroll
-    for (int n = 0; n < NI; ++n)
+    for (int pl = 0; pl < NPL; ++pl) {
+      const unsigned long long a = (unsigned long long)(uintptr_t)bp[pl];
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
+      for (int n = 0; n < NI; ++n) {
         unsigned short* dst = img + pl * BR * BK3 + ((n * 4 + w) * 16) * BK3;       // wave-uniform 1-KiB block
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[pl], (__attribute__((address_space(3))) void*)dst, 16, voff[n], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff[n], soff, 0, 0);
       }
+    }
   }
   template <int AUX = 0>      // (same call form as Bf3Loader; the builtin itself sits in a non-template member: the host pass of the compiler rejects it inside one)
   __device__ __forceinline__ void issue(int k0, unsigned short* img) const {
@@ -453,9 +466,14 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 // (scripts/bench_bf3_pipe_ablate.py) - a global_load_lds that cannot issue (address arithmetic, M0 set-up, a full
 // vector-memory queue) blocks the MFMAs queued behind it in the same wave.  A producer wave that blocks costs nothing.
 // Two waves per SIMD, so the kernel has to fit 256 registers; the stores of a seam and the DMA no longer share a vmcnt.
-template <int AK, int ABL = 0, int NST = 3, int FMT = 0>      // FMT: operand format (top of the file); ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
-__global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
+// NPW (on-the-fly operand only): producer waves, 4 or 8.  With four, a producer thread transforms 16 values per K tile - ~150 dependent
+// vector instructions between "the slot's data has arrived" and "its LDS image is written", longer than the computing wave's 24 MFMAs
+// of the same K tile: the producer, not the matrix pipe, set the pace (1.34 us per K tile against 0.83 us for the plane kernel).  Eight
+// producer waves (two per SIMD beside the computing wave: 768 threads, <= 168 registers) halve that chain and overlap two of them per SIMD.
+template <int AK, int ABL = 0, int NST = 3, int FMT = 0, int NPW = 4, int DA_ = 4>      // DA_: input slots in flight per producer wave (on-the-fly operand); FMT: operand format (top of the file); ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
+__global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128;
+  static_assert(NPW == 4 || (NPW == 8 && AK == OPK_ROWK_BN), "eight producer waves: on-the-fly operand only");
   constexpr int NPL = Bf3Fmt<FMT>::NPL;       // planes per operand
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = NPL * APLANE, BOPER = NPL * BPLANE, STAGE = AOPER + BOPER;
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];
@@ -482,7 +500,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
   const int total = ntl * nkt + npk;
   if (total == 0) return;
   if constexpr (kBn) {     // scale / shift of every input channel -> LDS (all eight waves; one barrier, once per launch)
-    for (int k = tid; k < p.K; k += 512) { bn_tab[k] = p.a_scale[k]; bn_tab[kBnTabMax + k] = p.a_shift[k]; }
+    for (int k = tid; k < p.K; k += 256 + 64 * NPW) { bn_tab[k] = p.a_scale[k]; bn_tab[kBnTabMax + k] = p.a_shift[k]; }
     __syncthreads();
   }
 
@@ -498,7 +516,10 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     // (a load has DA - 1 K-tile periods to arrive: with two sets the kernel ran at the memory latency, 2.5 us per K tile)
     // Thread mapping of the 128 x 32 fp32 tile: a wave instruction reads 8 rows x 128 B (8 lanes x 16 B per row: whole cache
     // lines, every byte used once); thread (r8, kq) of producer wave pw holds channels 4*kq..4*kq+3 of rows pw*32 + 8*i + r8.
-    const int pt = tid - 256, prow0 = (pt >> 6) * 32 + ((pt & 63) >> 3), kq = pt & 7;
+    // (NPW = 8: 16 rows per producer wave, two rows per thread; only the first four producer waves issue the weight DMA)
+    constexpr int RPW = BM / NPW, NR = RPW / 8;      // rows per producer wave, rows per thread
+    const int pt = tid - 256, prow0 = (pt >> 6) * RPW + ((pt & 63) >> 3), kq = pt & 7;
+    const bool b_wave = (pt >> 6) < 4;               // wave-uniform
     __builtin_amdgcn_s_setprio(3);       // the transform's vector instructions ahead of the computing wave of the same SIMD (measured: no change
                                          // either way - the two instruction streams add up on the SIMD whatever their order)
     const bool has_res = p.a_res != nullptr;
@@ -516,31 +537,32 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     };
     It itb, itl;
     it_init(itb); it_init(itl);
-    { const int t = it_tile(itb); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); }
+    if (b_wave) { const int t = it_tile(itb); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); }
     auto issue_b = [&](unsigned short* stage) {
+      if (!b_wave) return;
       lbld.issue((itb.k0 + itb.kt) * BK3, stage + AOPER);
       if (it_next(itb) && itb.j < nwork) { const int t = it_tile(itb); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); }
     };
     // register set of one slot (DA instances; indices are compile-time constants after unrolling: no runtime-indexed register arrays)
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
     struct ASet {
-      f32x4_ ra[4], rr[4];                // raw values, residuals (row prow0 + 8 * i)
+      f32x4_ ra[NR], rr[NR];              // raw values, residuals (row prow0 + 8 * i)
       unsigned off0;                      // byte offset of the thread's first row in a_raw / a_res / a_out
       unsigned tab;                       // byte offset of the thread's first channel in the scale / shift table
       unsigned flg;                       // bits 0..3: row i inside the matrix, bit 4: this tile stores a_out, bit 5: ragged tile (wave-uniform)
     };
-    constexpr int DA = 4;                 // A slots in flight (register sets); slot s lives in set s % DA
+    constexpr int DA = DA_;               // A slots in flight (register sets); slot s lives in set s % DA
     ASet sets[DA];
     if (!has_res) {                       // the residual registers stay zero for the whole launch (the transform always adds them)
 #pragma unroll
       for (int d = 0; d < DA; ++d)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sets[d].rr[i] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NR; ++i) sets[d].rr[i] = f32x4_{0.f, 0.f, 0.f, 0.f};
     }
     // loader state of the tile `itl` is in: 32-bit byte offsets (the host checks M * ld * 4 < 2^32) of the thread's four rows
     // (clamped to the last row of the matrix) at channel 4 * kq, and the flags every slot of the tile carries
     const unsigned ldb = (unsigned)p.a_ld * 4u;
-    unsigned lrow[4], lrow0 = 0, lflg = 0;
+    unsigned lrow[NR], lrow0 = 0, lflg = 0;
     auto load_tile = [&]() {
       const int t = it_tile(itl), tm = t / p.ntiles, tn = t - tm * p.ntiles;
       const int gr = tm * BM + prow0;
@@ -548,10 +570,10 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       // the fp32 copy of the input (a_out) is written once per row block: by the N tile that "owns" this producer wave's 32 rows - the
       // four waves are dealt over the first min(ntiles, 4) N tiles of the row block, so that sibling tiles carry the same store load and
       // stay in step (they read the same input rows: in step, the second read hits L2; until round 4 the tn == 0 tile stored everything)
-      const int owner = ((pt >> 6) * min(p.ntiles, 4)) >> 2;
+      const int owner = ((prow0 >> 5) * min(p.ntiles, 4)) >> 2;      // (prow0 >> 5: the 32-row quarter of the row block this thread works in)
       lflg = ((tn == owner && p.a_out != nullptr) ? 16u : 0u) | ((tm * BM + BM > p.M) ? 32u : 0u);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         lflg |= (gr + 8 * i < p.M) ? (1u << i) : 0u;
         lrow[i] = (unsigned)min(gr + 8 * i, p.M - 1) * ldb + (unsigned)kq * 16u;
       }
@@ -563,13 +585,13 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       // (inline asm: a load the compiler can see gets a compiler-placed vmcnt(0) at its first use - it cannot count across this
       //  control flow - which drains every slot in flight; the counted waits below are followed by a statement naming the registers)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         const unsigned vo = lrow[i] + kb;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.ra[i]) : "v"(vo), "s"(p.a_raw) : "memory");
       }
       if (has_res) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
           const unsigned vo = lrow[i] + kb;
           asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.rr[i]) : "v"(vo), "s"(p.a_res) : "memory");
         }
@@ -578,9 +600,9 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     };
     // LDS image: row r of a plane is 64 B (32 bf16); its 16-B chunk c sits at position c ^ ((r >> 2) & 3); the thread's 4 values
     // are the 8-B half (kq & 1) of chunk kq >> 1
-    unsigned doff[4];
+    unsigned doff[NR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const unsigned r = (unsigned)(prow0 + 8 * i);
       doff[i] = r * 64u + ((((unsigned)kq >> 1) ^ ((r >> 2) & 3u)) << 4) + ((unsigned)kq & 1u) * 8u;
     }
@@ -597,10 +619,10 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
       typedef float f32x2_ __attribute__((ext_vector_type(2)));
       typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
-      float v[4][4];
+      float v[NR][4];
       const f32x2_ s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w}, t01 = {t4.x, t4.y}, t23 = {t4.z, t4.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         const f32x4_ x = S.ra[i], q = S.rr[i];
         const f32x2_ a01 = f32x2_{x.x, x.y} * s01 + t01 + f32x2_{q.x, q.y}, a23 = f32x2_{x.z, x.w} * s23 + t23 + f32x2_{q.z, q.w};    // packed fp32 fma / add
         v[i][0] = fmaxf(a01.x, relu_floor); v[i][1] = fmaxf(a01.y, relu_floor);
@@ -609,21 +631,19 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
       if constexpr (FMT == 1) {
         // overflow guard (common.h): the values are >= 0 here (a_relu) or at least no NaN survives fmaxf, so the largest of the
         // sixteen decides - 8 vector instructions and a branch per slot instead of a compare per value
-        float mx = fmaxf(fmaxf(fabsf(v[0][0]), fabsf(v[0][1])), fabsf(v[0][2]));
-        mx = fmaxf(fmaxf(mx, fabsf(v[0][3])), fabsf(v[1][0])); mx = fmaxf(fmaxf(mx, fabsf(v[1][1])), fabsf(v[1][2]));
-        mx = fmaxf(fmaxf(mx, fabsf(v[1][3])), fabsf(v[2][0])); mx = fmaxf(fmaxf(mx, fabsf(v[2][1])), fabsf(v[2][2]));
-        mx = fmaxf(fmaxf(mx, fabsf(v[2][3])), fabsf(v[3][0])); mx = fmaxf(fmaxf(mx, fabsf(v[3][1])), fabsf(v[3][2]));
-        mx = fmaxf(mx, fabsf(v[3][3]));
+        float mx = fabsf(v[0][0]);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v[i][0])), fmaxf(fabsf(v[i][1]), fabsf(v[i][2]))), fabsf(v[i][3]));
         if (mx > kF16Max / kF16ActScale) f16x2_raise(p.status, 4u);
       }
       if (__builtin_amdgcn_readfirstlane(S.flg) & 32u) {        // last M tile of a ragged matrix: rows past the end are zero
         asm volatile("" ::: "memory");                           // (keeps this a branch: 16 selects per slot otherwise)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NR; ++i)
           if (!((S.flg >> i) & 1u)) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         if ((S.flg & 16u) && ((S.flg >> i) & 1u))
           *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.a_out) + (size_t)(S.off0 + (unsigned)(8 * i) * ldb)) =
               make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
@@ -669,8 +689,7 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
     // registers of the slot just released: every use of them is ordered behind it.  (A wait with the registers as operands in each
     // branch arm made the compiler copy the whole set - before the wait, i.e. before the data had arrived.)
 #define DIC_PIN_SLOT(S_)                                                                                                          \
-  asm volatile("" : "+v"((S_).ra[0]), "+v"((S_).ra[1]), "+v"((S_).ra[2]), "+v"((S_).ra[3]), "+v"((S_).rr[0]), "+v"((S_).rr[1]),   \
-               "+v"((S_).rr[2]), "+v"((S_).rr[3]) :: "memory")
+  do { _Pragma("unroll") for (int i_ = 0; i_ < NR; ++i_) asm volatile("" : "+v"((S_).ra[i_]), "+v"((S_).rr[i_]) :: "memory"); } while (0)
     // ---- prologue (drains once per launch): slot 0 transformed, its register set reloaded
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DIC_PIN_SLOT(sets[0]);
@@ -693,7 +712,9 @@ __global__ void __launch_bounds__(512) gemm_bf3_persist_ws_kernel(const Bf3Param
         //  much younger; no test ever caught a late tile, the weights come from L2 within two K tiles, but nothing guaranteed it.)
         if (g + 1 < total) {
           if (steady_ok && g >= 2 && g + DA < total) {
-            if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 8 + 2 * NPL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 4 + 2 * NPL) : "memory");
+            // (waves without the weight DMA - NPW = 8 - only need L(g+1): the DA - 1 younger loads may stay in flight)
+            if (b_wave) { if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NR + 2 * NPL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR + 2 * NPL) : "memory"); }
+            else { if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 2 * NR) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * NR) : "memory"); }
           } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
@@ -1341,212 +1362,18 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// "A-stationary" 1x1 convolution with a short contraction and the BatchNorm-apply of its input fused in:
-//     y[M][N] = relu(raw[M][K] * scale[K] + shift[K]) . W[N][K]^T ,   K = 32 * KT <= 256, N % 128 == 0     (f16x2 operand format)
-// - the bottleneck expansions conv3 of ResNet layers 2 and 3 (K = 128 / 256, N = 4 K; 44 of the 50 conv3 launches).  Until round 4 they
-// cost a bn_apply_planes pass (read raw conv2 output, write two fp16 planes) plus a plane kernel that streams A and B tiles through a ring
-// for only 4 / 8 K tiles per output tile (28 us at layer 3 for 11 us of matrix work: prologue / drain per tile and the 51-MB output write).
-// Here a workgroup owns a 64-row block of the input for ALL N: the producer waves read its raw fp32 rows ONCE (64 x K floats), normalise,
-// rectify, split and leave the two fp16 planes resident in LDS (64 KB at K = 256) - no pass, no planes in HBM, no re-transform per N
-// tile (what made the on-the-fly operand of gemm_bf3_persist_ws_kernel a loss for conv3: 8 N tiles = 8 transforms) - and only the
-// weights stream (LDS-DMA ring, 3 stages of two K tiles = 32 KB; the whole W is 1 MB and L2-resident).  One long loop of
-// N/128 x K/64 stage steps per workgroup, 24 MFMAs per computing wave between barriers as in the persistent kernels, an output tile
-// stored every K/64 steps while the ring keeps running.  Computing waves: 2 x 2, 32 rows x 64 columns each.
-// Summation order per output element = the plane kernels' (K tiles in order, k-steps in order, products h2*h1', h1*h2', h1*h1'), and the
-// operand values are bn_apply_planes' (fma, max, split2_f16): bit-identical to the plane route.  BatchNorm partial sums per 32-row wave
-// tile: [2 * ceil(M / 64)][2][N].  LDS: 2 * 64 * K * 2 B + 96 KB = 160 KB at K = 256.
-template <int KT>
-__global__ void __launch_bounds__(512) conv1x1_astat_bn_kernel(const Bf3Params p) {
-  constexpr int BM = 64, BN = 128, NPL = 2, NSTB = 3, K = KT * 32;
-  constexpr int APLANE = BM * K;                      // elements per plane of the resident A image: [KT][64 rows][32]
-  constexpr int BTILE = NPL * BN * BK3;               // one K tile of B as the loader lays it out: [plane][128][32] (16 KB)
-  constexpr int BSTAGE = 2 * BTILE;                   // a ring stage = two K tiles
-  constexpr int SPN = KT / 2;                         // stage steps per 128-column N tile
-  constexpr int NB = 2 * 2 * NPL;                     // DMA instructions per producer wave and stage
-  __shared__ __align__(1024) unsigned short smem[NPL * APLANE + NSTB * BSTAGE];
-  unsigned short* const bring = smem + NPL * APLANE;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tm = xcd_remap(blockIdx.x, gridDim.x);
-  const int NT = p.N / BN, S = NT * SPN;              // stage steps of this workgroup
-
-  if (wave >= 4) {
-    // ================= producer waves
-    const int pw = wave - 4;
-    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
-    int sb = 0;
-    auto issue_b = [&](unsigned short* stage) {
-      const int tn = sb / SPN, kp = sb - tn * SPN;
-      if (kp == 0) lbld.init(p.B, tn * BN, p.N, p.K);
-      lbld.issue(kp * 64, stage);
-      lbld.issue(kp * 64 + 32, stage + BTILE);
-      ++sb;
-    };
-#pragma unroll
-    for (int s0 = 0; s0 < NSTB; ++s0)
-      if (s0 < S) issue_b(bring + s0 * BSTAGE);
-    // ---- the A block, once: thread (r8, kq) of producer wave pw takes channels 4*kq .. 4*kq+3 of every K tile for rows pw*16 + r8 and
-    // pw*16 + r8 + 8 (a wave instruction reads 8 rows x 128 B: whole cache lines)
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const int r8 = lane >> 3, kq = lane & 7;
-    f32x4_ xa[KT][2], sc[KT], sh[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int gr = min(tm * BM + pw * 16 + r8 + 8 * i, p.M - 1);
-        xa[kt][i] = *reinterpret_cast<const f32x4_*>(p.a_raw + (size_t)gr * p.a_ld + kt * 32 + kq * 4);
-      }
-      sc[kt] = *reinterpret_cast<const f32x4_*>(p.a_scale + kt * 32 + kq * 4);
-      sh[kt] = *reinterpret_cast<const f32x4_*>(p.a_shift + kt * 32 + kq * 4);
-    }
-    const float floor_ = p.a_relu ? 0.f : -__builtin_inff();
-    const unsigned abase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
-    bool bad = false;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rl = pw * 16 + r8 + 8 * i;
-        const bool in = tm * BM + rl < p.M;
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float a = fmaf(xa[kt][i][u], sc[kt][u], sh[kt][u]);             // = bn_apply_planes: fma, then the ReLU
-          v[u] = fmaxf(a, floor_);
-          bad |= (a != a) | f16x2_out_of_range(v[u], kF16ActScale);             // overflow guard (common.h); a NaN would not survive the fmaxf
-          v[u] = in ? v[u] : 0.f;                                               // rows past the end of the matrix: exact zeros
-        }
-        typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
-        typedef float f32x2_ __attribute__((ext_vector_type(2)));
-        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
-        u32x2_ q1, q2;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                                           // = split2_f16(v, kF16ActScale)
-          const f32x2_ xx = f32x2_{v[2 * u], v[2 * u + 1]} * kF16ActScale;
-          const f16x2_ h1 = __builtin_convertvector(xx, f16x2_);
-          const f32x2_ r1 = xx - __builtin_convertvector(h1, f32x2_);
-          q1[u] = __builtin_bit_cast(unsigned, h1); q2[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_));
-        }
-        const unsigned dst = abase + (unsigned)(kt * (BM * 64) + rl * 64) + ((((unsigned)kq >> 1) ^ (((unsigned)rl >> 2) & 3u)) << 4) + ((unsigned)kq & 1u) * 8u;
-        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(q1) : "memory");
-        asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(q2), "i"(APLANE * 2) : "memory");
-      }
-    if (bad) f16x2_raise(p.status, 4u);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               // A image written, ring stages 0..2 landed
-    __builtin_amdgcn_s_barrier();
-    for (int g = 0; g < S; ++g) {
-      // stage g+1 must have landed before the computing waves read it (after this barrier); stage g+2 may stay in flight
-      if (g + 2 < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                             // ... and they are done with stage g % NSTB
-      if (g + NSTB < S) issue_b(bring + (g % NSTB) * BSTAGE);
-    }
-    return;
-  }
-
-  // ================= computing waves
-  const int wm = wave >> 1, wn = wave & 1;
-  const int i31 = lane & 31, h = lane >> 5, key = (i31 >> 2) & 3;
-  const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
-  const unsigned offA = sbase0 + (unsigned)((wm * 32 + i31) * 64);
-  const unsigned offB = sbase0 + (unsigned)(NPL * APLANE * 2) + (unsigned)((wn * 64 + i31) * 64);
-  const unsigned pos[2] = {(unsigned)(((0 + h) ^ key) * 16), (unsigned)(((2 + h) ^ key) * 16)};
-  f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  u32x4 fa[2][2], fb[2][2][2];                      // [buffer][plane], [buffer][column tile][plane]
-  // fragments of k-step Q_ (0..3) of the ring stage at byte offset STB_, A K tile AKT_, into register buffer BUF_
-#define DIC_AS_READ(BUF_, AKT_, Q_, STB_)                                                                                         \
-  _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                                                              \
-      bf3_lds_read(fa[BUF_][pl], offA + (unsigned)(pl * APLANE * 2) + (unsigned)((AKT_) * (BM * 64)) + pos[(Q_) & 1]);            \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                \
-      bf3_lds_read(fb[BUF_][j][pl], offB + (STB_) + (unsigned)((((Q_) >> 1) * BTILE + pl * BN * BK3) * 2 + j * 32 * 64) + pos[(Q_) & 1]);
-#define DIC_AS_PIN(BUF_)                                                                                                          \
-  _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) { asm volatile("" : "+v"(fa[BUF_][pl]));                                     \
-    asm volatile("" : "+v"(fb[BUF_][0][pl])); asm volatile("" : "+v"(fb[BUF_][1][pl])); }
-#define DIC_AS_MFMA(BUF_, PA_, PB_)                                                                                               \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] = bf3_mfma<1>(fa[BUF_][PA_], fb[BUF_][j][PB_], acc[j]);
-#define DIC_AS_MFMA_ALL(BUF_) DIC_AS_MFMA(BUF_, 1, 0) DIC_AS_MFMA(BUF_, 0, 1) DIC_AS_MFMA(BUF_, 0, 0)
-  __builtin_amdgcn_s_barrier();                      // the A image and ring stage 0 are in LDS
-  DIC_AS_READ(0, 0, 0, 0u)
-  int kp = 0, tn = 0, st = 0;
-  for (int s = 0; s < S; ++s) {
-    const int stn = st == NSTB - 1 ? 0 : st + 1;
-    const unsigned stb = (unsigned)(st * BSTAGE * 2), stbn = (unsigned)(stn * BSTAGE * 2);
-    const int akt = kp * 2, aktn = kp == SPN - 1 ? 0 : akt + 2;
-    DIC_AS_READ(1, akt, 1, stb)
-    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    DIC_AS_PIN(0)
-    __builtin_amdgcn_sched_barrier(0);
-    DIC_AS_MFMA_ALL(0)
-    __builtin_amdgcn_sched_barrier(0);
-    DIC_AS_READ(0, akt + 1, 2, stb)
-    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    DIC_AS_PIN(1)
-    __builtin_amdgcn_sched_barrier(0);
-    DIC_AS_MFMA_ALL(1)
-    __builtin_amdgcn_sched_barrier(0);
-    DIC_AS_READ(1, akt + 1, 3, stb)
-    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    DIC_AS_PIN(0)
-    __builtin_amdgcn_sched_barrier(0);
-    DIC_AS_MFMA_ALL(0)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this stage is in registers
-    DIC_AS_PIN(1)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    DIC_AS_MFMA(1, 1, 0)
-    if (s + 1 < S) { DIC_AS_READ(0, aktn, 0, stbn) }
-    DIC_AS_MFMA(1, 0, 1) DIC_AS_MFMA(1, 0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    st = stn;
-    if (++kp < SPN) continue;
-    kp = 0;
-    // ---- N tile tn is complete: unscale, store, BatchNorm partial sums of this wave's 32 rows (rows past M hold exact zeros)
-    const int n0 = tn * BN + wn * 64 + (lane & 31), m0 = tm * BM + wm * 32 + 4 * h;
-    const bool full = (tm + 1) * BM <= p.M;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      acc[j] *= p.ep.alpha;
-      float* col = p.ep.C + (long long)m0 * p.ep.ldc + n0 + j * 32;
-      float cs = 0.f, cs2 = 0.f;
-      if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[j][r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (m0 + (r & 3) + 8 * (r >> 2) < p.M) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[j][r];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { cs += acc[j][r]; cs2 += acc[j][r] * acc[j][r]; acc[j][r] = 0.f; }
-      if (p.ep.stats) {
-        const float a = cs + __shfl_xor(cs, 32, 64), b = cs2 + __shfl_xor(cs2, 32, 64);
-        if (lane < 32) {
-          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 0) * p.N + n0 + j * 32] = a;
-          p.ep.stats[((long long)(tm * 2 + wm) * 2 + 1) * p.N + n0 + j * 32] = b;
-        }
-      }
-    }
-    ++tn;
-  }
-#undef DIC_AS_READ
-#undef DIC_AS_PIN
-#undef DIC_AS_MFMA
-#undef DIC_AS_MFMA_ALL
-}
+#ifdef DIC_EXPERIMENTS
+#include "experiments/conv1x1_astat.inc"      // parked: A-stationary conv3 kernel with the BatchNorm-apply fused in (see the note in the file)
+#endif
 
 }  // namespace dic
 
 namespace dic {
 
 static int g_last_mtiles = 0;   // M tiles of the most recent launch (row count of the BN partial-sum table)
+#ifdef DIC_EXPERIMENTS
 void conv1x1_astat_switch(int on);
+#endif
 // Kernel-selection switches (dic_debug_force_staged_gemm, include/dic.h).  The product library keeps the ones its tests use to
 // compare kernels that the policy below really selects (tile forcing 11 / 21 / 24 / 20, persistent policy 70 / 73 / 79, halo
 // 74 / 75 / 78); the ablations and the parked kernels exist only in the experiments build (-DDIC_EXPERIMENTS).
@@ -1560,6 +1387,10 @@ static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K 
 static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
 static int g_bf3_remainder_grid = 256; // ... and the workgroups such a launch may use
 static int g_bf3_ws256 = 1;            // codes 80 / 81: 256x128 form of the warp-specialised kernel for f16x2 row-major plain-epilogue launches by policy (default) / never
+static int g_bf3_slots = 4;            // codes 114 / 115: input slots in flight per producer wave of the eight-producer form: 4 (default) / 6
+                                       // (eight do not fit 168 registers: the compiler spills, and a spilled destination of an in-flight
+                                       //  asm load is garbage - that build hung the kernel; build.py now refuses any spilling kernel)
+static int g_bf3_producers = 8;        // codes 112 / 113: producer waves of the f16x2 on-the-fly-operand kernel: 4 / 8 (default)
 #ifdef DIC_EXPERIMENTS
 static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
@@ -1598,8 +1429,10 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 20 || code == 11 || code == 21 || code == 24) { g_bf3_force = code == 20 ? 0 : code; return 0; }
   if (code == 90 || code == 91) { g_bf3_remainder_split = code - 90; return 0; }      // remainder-round K split of the persistent kernels off / on (default)
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
-  if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never / by shape (default)
+  if (code == 112 || code == 113) { g_bf3_producers = code == 112 ? 4 : 8; return 0; }      // f16x2 on-the-fly-operand kernel: four / eight (default) producer waves
+  if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }          // ... its input slots in flight per producer wave: four (default) / six
 #ifdef DIC_EXPERIMENTS
+  if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
   if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
@@ -1775,7 +1608,9 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
     const int grid = persist_grid;
     if (p.fmt == 1) {
-      if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
+      if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
+      else if (p.a_raw && g_bf3_producers == 8) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8>), dim3(grid), dim3(768), 0, st, p);
+      else if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
       else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
@@ -1854,9 +1689,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   return DIC_OK;
 }
 
+#ifdef DIC_EXPERIMENTS
 // conv3-style 1x1 convolution on the A-stationary kernel (conv1x1_astat_bn_kernel): y_raw[M][CO] = relu(raw[M][C] * scale + shift) . W^T,
 // f16x2 weights planes (scale in out_scale = 1 / (kF16ActScale * w_scale)); BatchNorm partials per 32-row wave tile: *mtiles_out rows
-static int g_astat = 1;                  // codes 110 / 111: off / on (default)
+static int g_astat = 0;                  // codes 110 / 111 (experiments build): off (default) / on
 void conv1x1_astat_switch(int on) { g_astat = on; }
 bool conv1x1_astat_eligible(int M, int C, int CO) {
   return g_astat != 0 && (C == 128 || C == 256) && CO % 128 == 0 && CO >= 128 && M >= 64 && (long long)(CO + 1) * C * 2 < (1ll << 31);
@@ -1885,6 +1721,7 @@ int conv1x1_astat_bn(const float* raw, const float* scale, const float* shift, i
   if (mtiles_out) *mtiles_out = 2 * mt;
   return DIC_OK;
 }
+#endif
 
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],

@@ -418,11 +418,10 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   100..104     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
  *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both / by operand
  *                format (default: both in mode 1, block outputs only in mode 2)
- *   110 111      mode 2: conv3 of ResNet layers 2 and 3 (K = 128 / 256) on the A-stationary kernel - the 64-row input block is
- *                normalised / rectified / split once inside the kernel and stays in LDS for all output columns - never / by shape
- *                (default; an explicit 100..103 keeps the routes it names)
+ *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
+ *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
- * 256x128 contraction forms, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
+ * 256x128 contraction forms, the A-stationary conv3 kernel of round 4, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes
  * listed in csrc/api.hip and csrc/gemm_bf3.hip); scripts/ load it with DIC_LIB=experiments, the product never does.
  * bf16x3 key of dic_profile_end: 2000 (f16x2 operand format: 3000) + 10*A_kind (6 = on-the-fly BatchNorm operand) + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,

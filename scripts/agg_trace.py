@@ -8,7 +8,8 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[[i for i, r in enumerate(rows) if "bn_relu_maxpool" in r["Kernel_Name"]][-1]:]
-KINDS = (("persist_ws_kernel<6", "ws6"), ("persist_ws_kernel<0", "ws0"), ("persist_ws_kernel<2", "ws2"), ("halo", "halo"),
+KINDS = (("astat", "astat"), ("ws256", "ws256"), ("bn_finalize_train", "bnfin"), ("bn_finalize_from", "bnfs"), ("bn_stats_slice", "bnss"), ("tail_fixup", "tailfx"),
+         ("persist_ws_kernel<6", "ws6"), ("persist_ws_kernel<0", "ws0"), ("persist_ws_kernel<2", "ws2"), ("halo", "halo"),
          ("bn_apply_planes", "bnp"), ("bn_apply_kernel", "bna"), ("gemm_bf3_kernel", "g64"))
 agg = collections.OrderedDict()
 tot = 0.0

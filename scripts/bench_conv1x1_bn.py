@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--fmt", type=int, default=0, help="operand format: 0 = bf16x3, 1 = f16x2")
 ap.add_argument("--switches", default="", help="comma-separated dic_debug_force_staged_gemm codes")
+ap.add_argument("--rotate", type=int, default=1, help="cycle through this many input / output buffer sets (> 256 MiB in total: no launch finds its operands in the Infinity Cache)")
 a = ap.parse_args()
 lib = _lib.load()
 for code in filter(None, a.switches.split(",")):
@@ -56,9 +57,11 @@ B = a.batch
 for name, M, Cin, CO in (("layer2 conv1", B * 784, 512, 128), ("layer2 conv3", B * 784, 128, 512), ("layer3 conv1", B * 196, 1024, 256),
                          ("layer3 conv3", B * 196, 256, 1024), ("layer4 conv1", B * 49, 2048, 512), ("layer4 conv3", B * 49, 512, 2048),
                          ("layer1 conv3", B * 3136, 64, 256)):
-    raw = torch.randn(M, Cin, device=DEV)
-    res = torch.randn(M, Cin, device=DEV)
-    out = torch.empty(M, Cin, device=DEV)
+    raws = [torch.randn(M, Cin, device=DEV) for _ in range(a.rotate)]
+    ress = [torch.randn(M, Cin, device=DEV) for _ in range(a.rotate)]
+    outs = [torch.empty(M, Cin, device=DEV) for _ in range(a.rotate)]
+    raw, res, out = raws[0], ress[0], outs[0]
+    turn = [0]
     scale = torch.rand(Cin, device=DEV) + 0.5
     shift = torch.randn(Cin, device=DEV)
     w = torch.randn(CO, Cin, device=DEV) / Cin ** 0.5
@@ -74,6 +77,8 @@ for name, M, Cin, CO in (("layer2 conv1", B * 784, 512, 128), ("layer2 conv3", B
 
     def fused(r, o):
         def f():
+            turn[0] = (turn[0] + 1) % a.rotate
+            raw, res, out = raws[turn[0]], ress[turn[0]], outs[turn[0]]
             rc = lib.dic_debug_conv1x1_bn_fmt(ptr(raw), ptr(scale), ptr(shift), ptr(res) if r else None, 1, ptr(out) if o else None, M, Cin, planes(wp),
                                               CO, ptr(y), ptr(part), C.byref(mt), ptr(tail), 1024, a.fmt, osc, stream_ptr())
             assert rc in (0, 1), rc

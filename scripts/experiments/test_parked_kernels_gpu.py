@@ -18,6 +18,7 @@ from depth_image_captioning_pub_amd import _lib, native, synthetic as syn      #
 from depth_image_captioning_pub_amd._lib import check, ptr, stream_ptr          # noqa: E402
 from oracle import captioning_oracle as orc                                      # noqa: E402
 from tests.test_decoder_gpu import _assert_close, _inputs, _to_dev              # noqa: E402
+import math                                                                      # noqa: E402
 
 DEV = "cuda:0"
 pytestmark = [pytest.mark.gpu,
@@ -107,3 +108,97 @@ def test_parked_tile_variants_are_bit_identical(lib, M, N, K):
         lib.dic_debug_force_staged_gemm(20)
     for code in (23, 2477, 26):
         assert torch.equal(outs[11], outs[code]), f"parked variant {code} differs from the 64x64 kernel"
+
+
+@pytest.mark.parametrize("M,Cin,CO", [(12544, 256, 1024), (50176, 128, 512), (12500, 256, 1024), (392, 256, 1024), (6272, 128, 512), (64, 256, 128)])
+def test_conv1x1_a_stationary_kernel(lib, M, Cin, CO):
+    """conv1x1_astat_bn_kernel (round 4; ResNet conv3 of layers 2 and 3 in the f16x2 format): y = relu(raw * scale + shift) . W^T with the
+    64-row input block normalised / rectified / split ONCE inside the kernel and resident in LDS for all output columns.  Against fp64,
+    against the plane route on the same kernel family (dic_split_f16x2_paired of the torch-evaluated activation -> dic_debug_conv_fmt;
+    printed: whether the outputs are bit-identical), BatchNorm partial sums (per 32-row wave tile) against the stored output; ragged
+    last row blocks (12500, 392) leave rows past M untouched."""
+    assert lib.dic_debug_force_staged_gemm(111) == 0          # the parked kernel is off unless asked for
+    g = torch.Generator().manual_seed(M + Cin)
+    raw = torch.randn(M, Cin, generator=g).to(DEV)
+    scale = (torch.rand(Cin, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cin, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(CO, Cin, generator=g) / Cin ** 0.5).to(DEV)
+    act = torch.relu(torch.addcmul(shift, raw, scale))
+    w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
+    wp = [torch.zeros((CO + 1) // 2 * 2 * Cin, dtype=torch.int16, device=DEV) for _ in range(2)]
+    check(lib.dic_split_f16x2_paired(ptr(w), C.c_longlong(CO), Cin, C.c_float(w_scale), ptr(wp[0]), ptr(wp[1]), stream_ptr()), "split w")
+    wpl = (C.c_void_p * 3)(wp[0].data_ptr(), wp[1].data_ptr(), None)
+    pad = 3                                                        # canary rows behind the matrix
+    y = torch.full((M + pad, CO), float("nan"), device=DEV)
+    rows = 2 * ((M + 63) // 64)
+    part = torch.full((rows * 2 * CO,), float("nan"), device=DEV)
+    mt = C.c_int(0)
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    rc = lib.dic_debug_conv1x1_astat(ptr(raw), ptr(scale), ptr(shift), 1, M, Cin, wpl, CO, ptr(y), ptr(part), C.byref(mt),
+                                     C.c_float(1.0 / (4.0 * w_scale)), ptr(word), stream_ptr())
+    assert rc == 0, (rc, lib.dic_last_error())
+    torch.cuda.synchronize()
+    assert mt.value == rows and int(word.item()) == 0
+    assert torch.isnan(y[M:]).all(), "rows past M were written"
+    y = y[:M]
+    assert torch.isfinite(y).all()
+    ref64 = act.double().cpu() @ w.double().cpu().t()
+    sc = float(ref64.abs().max())
+    err = float((y.double().cpu() - ref64).abs().max()) / sc
+    yd = y.double().cpu()
+    stats = part.view(rows, 2, CO).double().sum(0).cpu()
+    assert torch.allclose(stats[0], yd.sum(0), rtol=1e-5, atol=1e-4 * sc) and torch.allclose(stats[1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4 * sc)
+    # the plane route on the same values
+    xp = [torch.zeros((M + 1) // 2 * 2 * Cin, dtype=torch.int16, device=DEV) for _ in range(2)]
+    check(lib.dic_split_f16x2_paired(ptr(act), C.c_longlong(M), Cin, C.c_float(4.0), ptr(xp[0]), ptr(xp[1]), stream_ptr()), "split x")
+    y2 = torch.zeros(M, CO, device=DEV)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    xpl = (C.c_void_p * 3)(xp[0].data_ptr(), xp[1].data_ptr(), None)
+    check(lib.dic_debug_conv_fmt(xpl, 1, 1, M, Cin, wpl, CO, 1, 1, 0, ptr(y2), None, None, ptr(tail), 1, C.c_float(1.0 / (4.0 * w_scale)),
+                                 stream_ptr()), "plane route")
+    torch.cuda.synchronize()
+    err2 = float((y2.double().cpu() - ref64).abs().max()) / sc
+    print(f"\n{M}x{CO}x{Cin} A-stationary: max err / scale vs fp64 {err:.2e} (plane route {err2:.2e}); bit-identical to the plane route: "
+          f"{bool(torch.equal(y, y2))}")
+    assert err < 4e-6 and err <= 2.0 * err2 + 1e-6
+    # a value beyond the fp16 range of the planes raises the guard word; shapes that are not this kernel's are refused (nothing launched)
+    raw2 = raw.clone(); raw2[5, 7] = 1.0e6
+    word.zero_()
+    assert lib.dic_debug_conv1x1_astat(ptr(raw2), ptr(scale), ptr(shift), 1, M, Cin, wpl, CO, ptr(y), ptr(part), C.byref(mt),
+                                       C.c_float(1.0 / (4.0 * w_scale)), ptr(word), stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert int(word.item()) != 0
+    assert lib.dic_debug_conv1x1_astat(ptr(raw), ptr(scale), ptr(shift), 1, M, 64, wpl, CO, ptr(y), None, None, C.c_float(1.0), None,
+                                       stream_ptr()) == 1
+    lib.dic_debug_force_staged_gemm(110)
+
+
+def test_resnet_forward_conv3_on_the_a_stationary_kernel_matches_plane_route(lib):
+    """Round 4: in the f16x2 format conv3 of ResNet layers 2 and 3 runs on conv1x1_astat_bn_kernel (switch 111, default) instead of
+    bn_apply_planes + the twelve-wave plane kernel (110).  Same operand values, same products, same summation order per output element -
+    what differs is the granularity of the BatchNorm partial sums (32-row instead of 64-row wave tiles: another association of the
+    same fp32 column sums), i.e. rounding level, amplified through the following BatchNorm layers like any reordering: the feature map
+    agrees to 2e-3 of its scale (the bound the folding test above uses for re-associated sums), running statistics to 1e-4, and each
+    route reproduces itself bit for bit."""
+    w = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(64, seed=123).to(DEV)
+    results = {}
+    try:
+        for code in (110, 111, 111, 110):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            wd = {k: v.to(DEV) for k, v in w.items()}
+            y = native.ResNetRunner(wd, conv_mode="f16x2").forward(imgs, train_bn=True, compact=True)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all()
+            stats = torch.cat([wd[k].flatten() for k in sorted(wd) if "running" in k])
+            if code in results:
+                assert torch.equal(results[code][0], y) and torch.equal(results[code][1], stats), f"switch {code} does not reproduce itself"
+            results[code] = (y.clone(), stats.clone())
+    finally:
+        lib.dic_debug_force_staged_gemm(110)
+    (y0, s0), (y1, s1) = results[110], results[111]
+    dy, ds = float((y1 - y0).abs().max()) / float(y0.abs().max()), float((s1 - s0).abs().max()) / float(s0.abs().max())
+    print(f"\nconv3 A-stationary vs plane route: features max |d| / max = {dy:.2e}, running statistics {ds:.2e}")
+    assert dy < 2e-3 and ds < 1e-4, (dy, ds)
+
+

@@ -94,10 +94,10 @@ def test_unknown_debug_switch_is_rejected():
     decoder loop, 1 register-staged kernel everywhere) belong to the experiments build.  No GPU call involved."""
     lib = ctypes.CDLL(build.build())
     lib.dic_last_error.restype = ctypes.c_char_p
-    for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 121):
+    for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 121, 110, 111):
         assert lib.dic_debug_force_staged_gemm(code) != 0, code
         assert b"unknown" in lib.dic_last_error()
-    for code in (11, 21, 24, 70, 75, 74, 90, 81, 100, 101, 102, 103, 110, 20, 78, 76, 73, 79, 91, 104, 80, 111):  # (ending on the defaults)
+    for code in (11, 21, 24, 70, 75, 74, 90, 81, 100, 101, 102, 103, 112, 115, 20, 78, 76, 73, 79, 91, 104, 80, 113, 114):  # (ending on the defaults)
         assert lib.dic_debug_force_staged_gemm(code) == 0, code
 
 
@@ -111,11 +111,19 @@ def test_device_code_has_no_defective_packed_fp32_forms():
     assert "probe_pk_fp32" not in found and "decoder_persist" not in found      # (experiments library only)
 
 
+def test_no_hand_scheduled_kernel_spills_registers():
+    """build.py refuses kernels that spill vector registers: inline-asm loads with hand-counted vmcnt do not survive the compiler
+    moving their destination registers to scratch (round 4: a spilling variant hung on the device).  The one exemption is named."""
+    build.build()
+    spills = build.audit_register_spills()
+    assert all("conv1_wgrad_kernel" in k for k in spills), spills
+
+
 def test_product_library_holds_no_parked_or_probe_code():
     """The parked kernels and the defect reproducer are built into libdic_experiments.so only (build.py --experiments)."""
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
-    for needle in ("probe", "pipe_kernel", "persist_kernel", "decoder_fwd_persistent", "dic_debug_decoder_stamps"):
+    for needle in ("probe", "pipe_kernel", "persist_kernel", "decoder_fwd_persistent", "dic_debug_decoder_stamps", "astat"):
         assert needle not in out, needle
     # the 256x128 twelve-wave kernel left the parked set in round 3 - in one instantiation: row-major operands, f16x2 format
     ws256 = sorted({w for w in out.split() if "ws256" in w})
