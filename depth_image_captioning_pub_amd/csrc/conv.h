@@ -29,7 +29,9 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
                  const float* bias = nullptr, const BnFuseArgs* bn_fuse = nullptr, int* bn_fused = nullptr,
                  int act = 0 /* ACT_NONE */, int tail_ws_slabs = 256 /* [64][64]-float slabs in tail_ws (kGemmTailWsBytes = 256) */,
                  int fmt = 0 /* operand format: 0 = bf16x3, 1 = f16x2 (two fp16 planes of scaled values, gemm_bf3.hip) */,
-                 float out_scale = 1.0f /* f16x2: 1 / (scale of the x planes * scale of the w planes) */);
+                 float out_scale = 1.0f /* f16x2: 1 / (scale of the x planes * scale of the w planes) */,
+                 const float* alpha_dev0 = nullptr, const float* alpha_dev1 = nullptr /* f16x2: further factors of the result scale that live
+                                                                                         in device memory (GemmEpilogue::alpha_dev) */);
 // 1x1 convolution with the BatchNorm-apply (+ residual) + ReLU + split of its input fused into the operand path (gemm_bf3.hip);
 // returns 1 (nothing launched) when the shape would not run on the persistent warp-specialised kernel
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
@@ -53,7 +55,8 @@ constexpr int kResnetTailSlabs = 1024;      // the ResNet workspace carves a lar
 size_t conv_wgrad_bf3_plane_elems(const ConvDesc& d, int which);
 size_t conv_wgrad_bf3_ws_floats(const ConvDesc& d, int splitk);
 int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk,
-                   unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st);
+                   unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st,
+                   int fmt = 0, const float* dy_slot = nullptr /* f16x2: the gradient's device-resident {scale, 1 / scale} (F16Scale::slot) */);
 // 7x7 stride-2 pad-3 stem with C_in = 3 on the bf16x3 kernel (strip formulation, see gemm_bf3.hip)
 size_t conv_stem_bf3_plane_elems(int B, int H, int W);
 int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st);
@@ -61,7 +64,7 @@ int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned 
                   const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st);
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
                       const unsigned short* const wflip_planes[3], float* dx, hipStream_t st, float* tail_ws = nullptr,
-                      int tail_ws_slabs = 256);
+                      int tail_ws_slabs = 256, int fmt = 0, const float* alpha_dev0 = nullptr, const float* alpha_dev1 = nullptr);
 int split_bf16x3(const float* x, long long n, unsigned short* hi, unsigned short* mid, unsigned short* lo, hipStream_t st);
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,
                         unsigned short* lo, hipStream_t st);

@@ -37,12 +37,17 @@ static DepthGeom depth_geom(int B, int H, int W) {
   return g;
 }
 
+static int g_depth_f16x2 = 1;      // codes 116 / 117: conv2 / conv3 of the depth encoder in bf16x3 / f16x2 (default) arithmetic
+void depth_encoder_f16x2(int on) { g_depth_f16x2 = on; }
 constexpr int kWg1Split = 128;   // split-K of the conv1 weight gradient (K = B*73*73)
 constexpr int kWg2Split = 4;
 constexpr int kWg2SplitBf3 = 5;   // conv2 weight gradient on the bf16x3 kernel: 144 output tiles x 5 K slices
 constexpr int kWg3SplitBf3 = 3;   // conv3: 256 tiles x 3
 
 struct DepthWs {
+  unsigned* status;                  // first word of the workspace: the f16x2 overflow guard (common.h), as in the ResNet workspace
+  unsigned* bounds;                  // f16x2 scales chosen on the device (F16Scale, nn_kernels.h): bound words 0 w2, 1 w3, 2 dy3, 3 dy2
+  float* slots;                      // ... and their {s, 1 / s} slots (2 floats each, same order)
   float *x1, *y1p, *x2, *y2p, *x3, *partial;
   double* red;
   unsigned char *idx1, *idx2;
@@ -68,6 +73,9 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   Carver c(p, bytes);
   DepthWs w{};
   const long long B = g.B;
+  w.status = c.take<unsigned>(64);
+  w.bounds = c.take<unsigned>(64);
+  w.slots = c.take<float>(64);
   w.x1 = c.take<float>((size_t)g.M1 * 128);
   w.y1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
   w.idx1 = c.take<unsigned char>((size_t)B * g.P1h * g.P1w * 128);
@@ -433,7 +441,7 @@ size_t dic_depth_encoder_workspace_bytes(int B, int H, int W) {
 // (the 6.5 MB of parameters stay in L2).
 struct DepthWeightPlanes { unsigned short *w2[3], *w2f[3], *w3[3], *w3f[3]; };
 __global__ void __launch_bounds__(256) depth_prepare_weights_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
-                                                                    DepthWeightPlanes pl) {
+                                                                    DepthWeightPlanes pl, const float* __restrict__ slots) {      // slots != NULL: f16x2 planes, scales slots[0] (w2), slots[2] (w3)
   constexpr int O2 = 512, I2 = 128, O3 = 2048, I3 = 512;
   constexpr long long n2 = (long long)O2 * I2 * 9, n3 = (long long)O3 * I3;
   constexpr long long q2 = n2 / 4, q3 = n3 / 4;              // groups of 4 consecutive elements per plane set
@@ -465,12 +473,18 @@ __global__ void __launch_bounds__(256) depth_prepare_weights_kernel(const float*
       }
     }
     unsigned short h[4], m[4], l[4];
+    if (slots) {
+      const float fs = slots[set < 2 ? 0 : 2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) split3_bf16(v[u], h[u], m[u], l[u]);
+      for (int u = 0; u < 4; ++u) split2_f16(v[u], fs, h[u], m[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) split3_bf16(v[u], h[u], m[u], l[u]);
+    }
     unsigned short* const* pp = set == 0 ? pl.w2 : set == 1 ? pl.w2f : set == 2 ? pl.w3 : pl.w3f;
     *reinterpret_cast<uint2*>(pp[0] + idx) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
     *reinterpret_cast<uint2*>(pp[1] + idx) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-    *reinterpret_cast<uint2*>(pp[2] + idx) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    if (!slots) *reinterpret_cast<uint2*>(pp[2] + idx) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
   }
 }
 
@@ -486,12 +500,27 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
   DepthWs ws = depth_carve(workspace, workspace_bytes, g, &ov);
   DIC_REQUIRE(!ov, "depth_encoder_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
   int mt = 0;
+  // Arithmetic of conv2 / conv3 (forward, data gradient, weight gradient: 91 % of the encoder's FLOPs): the f16x2 operand format of
+  // gemm_bf3.hip since round 4 (switch 117, default; 116 = the exact bf16x3 split of rounds 1-3) - half the matrix-core work.  The
+  // operands' power-of-two scales: activations kF16ActScale (guarded: status word at offset 0 of this workspace), the TRAINED weights
+  // and the gradients a scale chosen on the device every step (F16Scale: the weights' from their exact maximum, a gradient's from a
+  // bound its BatchNorm-backward computes before it splits), read by the contraction epilogues from memory - no host synchronisation.
+  const int fmt = g_depth_f16x2;
+  DIC_TRY(clear_status(ws.status, st));
+  const F16Scale s_w2{ws.bounds + 0, ws.slots + 0}, s_w3{ws.bounds + 1, ws.slots + 2};
+  if (fmt) {
+    DIC_TRY(f16_scale_reset(ws.bounds, 2, st));
+    DIC_TRY(f16_scale_from_absmax(w->conv2_w, 512ll * 128 * 9, s_w2, st));
+    DIC_TRY(f16_scale_from_absmax(w->conv3_w, 2048ll * 512, s_w3, st));
+  }
   {
     DepthWeightPlanes pl;
     for (int i = 0; i < 3; ++i) { pl.w2[i] = ws.w2_pl[i]; pl.w2f[i] = ws.w2f_pl[i]; pl.w3[i] = ws.w3_pl[i]; pl.w3f[i] = ws.w3f_pl[i]; }
-    hipLaunchKernelGGL(depth_prepare_weights_kernel, dim3(2048), dim3(256), 0, st, w->conv2_w, w->conv3_w, pl);
+    hipLaunchKernelGGL(depth_prepare_weights_kernel, dim3(2048), dim3(256), 0, st, w->conv2_w, w->conv3_w, pl, fmt ? (const float*)ws.slots : nullptr);
     DIC_LAUNCH_CHECK();
   }
+  unsigned short* const y1p_out[3] = {ws.y1p_pl[0], ws.y1p_pl[1], fmt ? nullptr : ws.y1p_pl[2]};      // (third pointer NULL = f16x2 planes)
+  unsigned short* const y2p_out[3] = {ws.y2p_pl[0], ws.y2p_pl[1], fmt ? nullptr : ws.y2p_pl[2]};
   // conv1 (1->128, k7 s3) + BN + ReLU + maxpool3          (depth_models.py:19-20,36-39)
   if (conv1_depth_supported(g.c1))
     DIC_TRY(conv1_depth_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
@@ -499,31 +528,33 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
     DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, ws.red, st));
   else DIC_TRY(bn_finalize_eval(128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
-  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st, ws.y1p_pl));
+  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st, y1p_out, ws.status));
   // conv2 (128->512, k3) + BN + ReLU + maxpool3            (:21-22,40-43)
   //   on the bf16x3 kernel (fp32-accurate, ~1.4x the exact-fp32 MFMA rate): split the pooled activations and W2
   {
-    const unsigned short* xp[3] = {ws.y1p_pl[0], ws.y1p_pl[1], ws.y1p_pl[2]};
-    const unsigned short* wp[3] = {ws.w2_pl[0], ws.w2_pl[1], ws.w2_pl[2]};
+    const unsigned short* xp[3] = {ws.y1p_pl[0], ws.y1p_pl[1], fmt ? nullptr : ws.y1p_pl[2]};
+    const unsigned short* wp[3] = {ws.w2_pl[0], ws.w2_pl[1], fmt ? nullptr : ws.w2_pl[2]};
     DIC_TRY(conv_fwd_bf3(xp, g.c2, wp, ws.x2, train ? ws.partial : nullptr, &mt, ws.tail, st, w->conv2_b, nullptr, nullptr,
-                         ACT_NONE, kResnetTailSlabs));
+                         ACT_NONE, kResnetTailSlabs, fmt, 1.0f / kF16ActScale, fmt ? s_w2.slot + 1 : nullptr));
   }
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M2, 512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, ws.red, st));
   else DIC_TRY(bn_finalize_eval(512, w->bn2_w, w->bn2_b, s->rm2, s->rv2, ws.bn2, st));
-  DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st, ws.y2p_pl));
+  DIC_TRY(bn_relu_maxpool(ws.x2, B, g.H2, g.W2, 512, &ws.bn2, 1, 3, 3, 0, ws.y2p, ws.idx2, st, y2p_out, ws.status));
   // conv3 (512->2048, k1) + BN + ReLU + AdaptiveAvgPool(14) -> [B,196,2048]   (:23-24,44-47,54)
   //   on the bf16x3 kernel as well (1x1: OIHW == OHWI, so conv3_w is split as it stands)
   {
-    const unsigned short* xp[3] = {ws.y2p_pl[0], ws.y2p_pl[1], ws.y2p_pl[2]};
-    const unsigned short* wp[3] = {ws.w3_pl[0], ws.w3_pl[1], ws.w3_pl[2]};
+    const unsigned short* xp[3] = {ws.y2p_pl[0], ws.y2p_pl[1], fmt ? nullptr : ws.y2p_pl[2]};
+    const unsigned short* wp[3] = {ws.w3_pl[0], ws.w3_pl[1], fmt ? nullptr : ws.w3_pl[2]};
     DIC_TRY(conv_fwd_bf3(xp, g.c3, wp, ws.x3, train ? ws.partial : nullptr, &mt, ws.tail, st, w->conv3_b, nullptr, nullptr,
-                         ACT_NONE, kResnetTailSlabs));
+                         ACT_NONE, kResnetTailSlabs, fmt, 1.0f / kF16ActScale, fmt ? s_w3.slot + 1 : nullptr));
   }
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M3, 2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, ws.red, st));
   else DIC_TRY(bn_finalize_eval(2048, w->bn3_w, w->bn3_b, s->rm3, s->rv3, ws.bn3, st));
   //   pool_out == 0: BN + ReLU only, output = the [B, P2h*P2w, 2048] map (requires a square map)
   DIC_REQUIRE(pool_out != 0 || g.P2h == g.P2w, "depth_encoder_fwd_map: the feature map must be square");
   DIC_TRY(adaptive_avgpool(ws.x3, B, g.P2h, g.P2w, 2048, &ws.bn3, 1, pool_out ? pool_out : g.P2h, features, st));
+  if (fmt)      // the loud end of the overflow guard, as in dic_resnet_fwd: NaN features when a pooled activation left the fp16 range
+    DIC_TRY(poison_if_raised(features, (long long)B * (pool_out ? pool_out * pool_out : g.P2h * g.P2w) * 2048, ws.status, st));
   return DIC_OK;
 }
 
@@ -548,28 +579,35 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
   bool ov = false;
   DepthWs ws = depth_carve(workspace, workspace_bytes, g, &ov);
   DIC_REQUIRE(!ov, "depth_encoder_bwd: workspace too small");
+  // (same arithmetic as the forward that filled this workspace: its weight planes and weight scale slots are reused here)
+  const int fmt = g_depth_f16x2;
+  F16Scale s_dy3{ws.bounds + 2, ws.slots + 4}, s_dy2{ws.bounds + 3, ws.slots + 6};
+  const float *inv_w2 = ws.slots + 1, *inv_w3 = ws.slots + 3;
+  if (fmt) DIC_TRY(f16_scale_reset(ws.bounds + 2, 2, st));
+  unsigned short* const dy3_out[3] = {ws.dy3_pl[0], ws.dy3_pl[1], fmt ? nullptr : ws.dy3_pl[2]};
+  unsigned short* const dy2_out[3] = {ws.dy2_pl[0], ws.dy2_pl[1], fmt ? nullptr : ws.dy2_pl[2]};
   // layer 3
   DIC_TRY(adaptive_avgpool_bwd(d_features, B, g.P2h, g.P2w, 2048, pool_out ? pool_out : g.P2h, ws.dy3, st));
   DIC_TRY(relu_mask_bwd(ws.dy3, ws.x3, g.M3, 2048, ws.bn3, st));
-  DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st, ws.dy3_pl));
-  DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));   // OHWI == OIHW for 1x1
+  DIC_TRY(bn_backward(ws.dy3, ws.x3, g.M3, 2048, w->bn3_w, ws.bn3, gr->bn3_w, gr->bn3_b, ws.bn_ws, st, dy3_out, fmt ? &s_dy3 : nullptr));
+  DIC_TRY(conv_wgrad_bf3(ws.y2p, g.c3, ws.dy3, gr->conv3_w, kWg3SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st, fmt, s_dy3.slot));   // OHWI == OIHW for 1x1
   DIC_TRY(colsum_rows(ws.dy3, 2048, g.M3, 2048, gr->conv3_b, ws.cs_ws, st));
   // (flipped weight planes w3f_pl / w2f_pl were written by the forward's depth_prepare_weights_kernel: same workspace)
   {
-    const unsigned short* dp[3] = {ws.dy3_pl[0], ws.dy3_pl[1], ws.dy3_pl[2]};
-    const unsigned short* wp[3] = {ws.w3f_pl[0], ws.w3f_pl[1], ws.w3f_pl[2]};
-    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c3, wp, ws.dy2p, st, ws.tail, kResnetTailSlabs));
+    const unsigned short* dp[3] = {ws.dy3_pl[0], ws.dy3_pl[1], fmt ? nullptr : ws.dy3_pl[2]};
+    const unsigned short* wp[3] = {ws.w3f_pl[0], ws.w3f_pl[1], fmt ? nullptr : ws.w3f_pl[2]};
+    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c3, wp, ws.dy2p, st, ws.tail, kResnetTailSlabs, fmt, fmt ? s_dy3.slot + 1 : nullptr, fmt ? inv_w3 : nullptr));
   }
   // layer 2
   DIC_TRY(bn_pool_backward(ws.dy2p, ws.idx2, ws.x2, B, g.H2, g.W2, 512, 3, w->bn2_w, ws.bn2, gr->bn2_w, gr->bn2_b,
-                           ws.bn_ws, ws.dy2, st, ws.dy2_pl));
-  DIC_TRY(conv_wgrad_bf3(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st));
+                           ws.bn_ws, ws.dy2, st, dy2_out, fmt ? &s_dy2 : nullptr));
+  DIC_TRY(conv_wgrad_bf3(ws.y1p, g.c2, ws.dy2, ws.dw2o, kWg2SplitBf3, ws.wg_dyT, ws.wg_pT, ws.wg_bf3_ws, st, fmt, s_dy2.slot));
   DIC_TRY(ohwi_to_oihw(ws.dw2o, gr->conv2_w, 512, 128, 3, 3, st));
   DIC_TRY(colsum_rows(ws.dy2, 512, g.M2, 512, gr->conv2_b, ws.cs_ws, st));
   {
-    const unsigned short* dp[3] = {ws.dy2_pl[0], ws.dy2_pl[1], ws.dy2_pl[2]};
-    const unsigned short* wp[3] = {ws.w2f_pl[0], ws.w2f_pl[1], ws.w2f_pl[2]};
-    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c2, wp, ws.dy1p, st, ws.tail, kResnetTailSlabs));
+    const unsigned short* dp[3] = {ws.dy2_pl[0], ws.dy2_pl[1], fmt ? nullptr : ws.dy2_pl[2]};
+    const unsigned short* wp[3] = {ws.w2f_pl[0], ws.w2f_pl[1], fmt ? nullptr : ws.w2f_pl[2]};
+    DIC_TRY(conv_dgrad_s1_bf3(dp, g.c2, wp, ws.dy1p, st, ws.tail, kResnetTailSlabs, fmt, fmt ? s_dy2.slot + 1 : nullptr, fmt ? inv_w2 : nullptr));
   }
   // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
   DIC_TRY(bn_pool_backward(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,

@@ -59,6 +59,10 @@ struct GemmEpilogue {
   long long ldc2;
   int nsplit;
   float alpha;          // result scale (applied before bias)
+  // two more factors of the result scale that live in DEVICE memory (nullable): the inverse operand scales of f16x2 planes whose scale
+  // is chosen on the device (trained weights, gradients: the depth encoder).  Effective scale = alpha * *alpha_dev[0] * *alpha_dev[1];
+  // all three are powers of two, so the product is exact.  Read once per workgroup (ep_alpha, gemm_epilogue.h).
+  const float* alpha_dev[2];
 };
 
 struct GemmParams {

@@ -483,9 +483,10 @@ __device__ __forceinline__ void tail_fixup_tile(const GemmParams& p, const int t
   float o[4] = {0.f, 0.f, 0.f, 0.f};
   if (m < p.M) {
     const float e[4] = {v.x, v.y, v.z, v.w};
+    const float alpha = ep_alpha(p.ep);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (n + j < p.N) o[j] = finalize_store(p.ep, m, n + j, e[j]);
+      if (n + j < p.N) o[j] = finalize_store(p.ep, m, n + j, e[j], alpha);
   }
   if (p.ep.stats) {     // column sums / sums of squares over the tile's 64 rows: 8 groups of 8 rows, then the 8 groups
     sred[0][row][c4] = make_float4(o[0], o[1], o[2], o[3]);
@@ -552,6 +553,7 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
       for (int u = 0; u < 8; ++u) { a += (double)va[u]; b += (double)vb[u]; }
     }
     // remainder tile rows: value = sum of the K slices (slice order), statistics straight in fp64
+    const float tail_alpha = ep_alpha(p.ep);
     const int tn = c >> 6, col = c & 63;
     for (int tm = mt_reg; tm < p.mtiles; ++tm) {
       const long long q = (long long)(tm - mt_reg) * p.ntiles + tn;            // index among the remainder tiles
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
         float v = x[0];
 #pragma unroll
         for (int u = 1; u < NS; ++u) v += x[u];
-        v *= p.ep.alpha;         // as finalize_store (1, or the exact power-of-two unscale of the f16x2 operand format)
+        v *= tail_alpha;         // as finalize_store (1, or the exact power-of-two unscale of the f16x2 operand format)
         if (tm * 64 + row < p.M) { a += (double)v; b += (double)v * (double)v; }
       }
     }
@@ -717,7 +719,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) 
     float s = 0.f;
     for (int z = 0; z < p.splitk; ++z) s += p.ws[(long long)z * total + e];
     const int m = (int)(e / p.N), n = (int)(e - (long long)m * p.N);
-    finalize_store(p.ep, m, n, s);
+    finalize_store(p.ep, m, n, s, ep_alpha(p.ep));
   }
 }
 

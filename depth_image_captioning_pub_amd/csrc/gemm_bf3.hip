@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= p.ep.alpha;
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= ep_alpha(p.ep);
       }
     }
 #pragma unroll
@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= p.ep.alpha;
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= ep_alpha(p.ep);
     }
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
@@ -1317,7 +1317,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= p.ep.alpha;
+          for (int jj = 0; jj < 2; ++jj) acc[i][jj] *= ep_alpha(p.ep);
       }
     }
 #pragma unroll
@@ -1726,7 +1726,8 @@ int conv1x1_astat_bn(const float* raw, const float* scale, const float* shift, i
 // y_raw[B,OH,OW,CO] (fp32) = conv(x planes NHWC, w planes OHWI); BN partial sums like conv_fwd
 int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, const unsigned short* const w_planes[3],
                  float* y, float* bn_partial, int* mtiles_out, float* tail_ws, hipStream_t st, const float* bias,
-                 const BnFuseArgs* bn_fuse, int* bn_fused, int act, int tail_ws_slabs, int fmt, float out_scale) {
+                 const BnFuseArgs* bn_fuse, int* bn_fused, int act, int tail_ws_slabs, int fmt, float out_scale,
+                 const float* alpha_dev0, const float* alpha_dev1) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.KH * d.KW <= 32, "conv_fwd_bf3: needs NHWC input with C %% 32 == 0");
   Bf3Params p{};
   p.M = d.M(); p.N = d.CO; p.K = d.K();
@@ -1737,7 +1738,9 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
   p.ep = ep_store(y, d.CO, bias, act);
   p.ep.stats = bn_partial;
   p.fmt = fmt;
-  if (fmt == 1) p.ep.alpha = out_scale;      // 1 / (activation scale * weight scale): the f16x2 planes hold scaled values
+  if (fmt == 1) {      // 1 / (activation scale * weight scale): the f16x2 planes hold scaled values; factors chosen on the device come by pointer
+    p.ep.alpha = out_scale; p.ep.alpha_dev[0] = alpha_dev0; p.ep.alpha_dev[1] = alpha_dev1;
+  }
   if (bn_fused) *bn_fused = 0;
   DIC_TRY(launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
@@ -1800,7 +1803,8 @@ template <bool IM2COL>
 __global__ void __launch_bounds__(256) transpose_split_kernel(const float* __restrict__ x, long long ld, int M, int Kpad,
                                                                int ncols, ConvGeom g, unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
-                                                               unsigned short* __restrict__ lo) {
+                                                               unsigned short* __restrict__ lo, float f16_scale,
+                                                               const float* __restrict__ f16_slot) {      // lo == NULL: f16x2 planes of scale * x, scale = *f16_slot or f16_scale
   __shared__ float tile[32][33];
   const int m0 = blockIdx.x * 32;
   const int tid = threadIdx.x;
@@ -1837,12 +1841,18 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* __res
     const int c = 2 * q + parity;
     const long long row = (IM2COL ? (long long)tap * g.C : 0) + c0 + c;
     unsigned short h[4], mm[4], l[4];
+    if (!lo) {
+      const float fs = f16_slot ? f16_slot[0] : f16_scale;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split3_bf16(tile[quad * 4 + j][c], h[j], mm[j], l[j]);
+      for (int j = 0; j < 4; ++j) split2_f16(tile[quad * 4 + j][c], fs, h[j], mm[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3_bf16(tile[quad * 4 + j][c], h[j], mm[j], l[j]);
+    }
     const long long off = plane_offset(row, m0 + quad * 4, Kpad / 32, 1);
     *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
     *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)mm[0] | ((unsigned)mm[1] << 16), (unsigned)mm[2] | ((unsigned)mm[3] << 16));
-    *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    if (lo) *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
   }
 }
 
@@ -1856,21 +1866,25 @@ size_t conv_wgrad_bf3_ws_floats(const ConvDesc& d, int splitk) {
 }
 
 int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk,
-                   unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st) {
+                   unsigned short* const dyT[3], unsigned short* const pT[3], float* ws, hipStream_t st, int fmt, const float* dy_slot) {
   DIC_REQUIRE(!d.in_nchw && d.C % 32 == 0 && d.CO % 32 == 0, "conv_wgrad_bf3: NHWC input, C and CO %% 32");
+  DIC_REQUIRE(fmt == 0 || dy_slot, "conv_wgrad_bf3: the f16x2 format needs the scale slot of the gradient");
   const int M = d.M(), Kpad = (M + 31) / 32 * 32;
   const ConvGeom g = d.geom();
+  // f16x2: dY^T planes of (*dy_slot) * dY, patch^T planes of kF16ActScale * x (third plane pointer NULL tells the kernel the format)
   hipLaunchKernelGGL((transpose_split_kernel<false>), dim3(Kpad / 32, d.CO / 32), dim3(256), 0, st, dy, (long long)d.CO, M,
-                     Kpad, d.CO, g, dyT[0], dyT[1], dyT[2]);
+                     Kpad, d.CO, g, dyT[0], dyT[1], fmt ? nullptr : dyT[2], 1.0f, fmt ? dy_slot : nullptr);
   hipLaunchKernelGGL((transpose_split_kernel<true>), dim3(Kpad / 32, d.KH * d.KW * (d.C / 32)), dim3(256), 0, st, x,
-                     (long long)d.C, M, Kpad, d.C, g, pT[0], pT[1], pT[2]);
+                     (long long)d.C, M, Kpad, d.C, g, pT[0], pT[1], fmt ? nullptr : pT[2], kF16ActScale, (const float*)nullptr);
   DIC_LAUNCH_CHECK();
   Bf3Params p{};
   p.M = d.CO; p.N = d.K(); p.K = Kpad;
   for (int i = 0; i < 3; ++i) { p.A.p[i] = dyT[i]; p.B.p[i] = pT[i]; }
+  if (fmt) p.A.p[2] = p.B.p[2] = nullptr;
   p.A.kind = OPK_ROWK; p.A.ld = Kpad; p.A.paired = 1;
   p.B.kind = OPK_ROWK; p.B.ld = Kpad; p.B.paired = 1;
   p.ep = ep_store(dw_ohwi, d.K(), nullptr, ACT_NONE);
+  if (fmt) { p.fmt = 1; p.ep.alpha = 1.0f / kF16ActScale; p.ep.alpha_dev[0] = dy_slot + 1; }      // 1 / (s_dy * 4): the first factor lives on the device
   return launch_bf3(p, st, nullptr, splitk, ws);
 }
 
@@ -1943,12 +1957,13 @@ int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned 
 }
 
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
-                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st, float* tail_ws, int tail_ws_slabs) {
+                      const unsigned short* const wflip_planes[3], float* dx, hipStream_t st, float* tail_ws, int tail_ws_slabs,
+                      int fmt, const float* alpha_dev0, const float* alpha_dev1) {
   DIC_REQUIRE(d.stride == 1 && d.CO % 32 == 0, "conv_dgrad_s1_bf3: stride 1, CO %% 32");
   // full correlation of dY (an [OH,OW,CO] image) with the flipped kernel, padding KH-1-pad
   const ConvDesc dd{d.B, d.OH(), d.OW(), d.CO, d.C, d.KH, d.KW, 1, d.KH - 1 - d.pad, 0};
   return conv_fwd_bf3(dy_planes, dd, wflip_planes, dx, nullptr, nullptr, tail_ws, st, nullptr, nullptr, nullptr, ACT_NONE,
-                      tail_ws_slabs);
+                      tail_ws_slabs, fmt, 1.0f, alpha_dev0, alpha_dev1);
 }
 
 int split_bf16x3_paired(const float* x, long long rows, int K, unsigned short* hi, unsigned short* mid,

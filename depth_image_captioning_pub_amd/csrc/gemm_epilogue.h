@@ -6,9 +6,17 @@ namespace dic {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// epilogue for one output element; returns the stored value (BN statistics use it)
-__device__ __forceinline__ float finalize_store(const GemmEpilogue& ep, int m, int n, float v) {
-  v *= ep.alpha;
+// the result scale of a launch: the host factor times the (optional) device-resident ones
+__device__ __forceinline__ float ep_alpha(const GemmEpilogue& ep) {
+  float a = ep.alpha;
+  if (ep.alpha_dev[0]) a *= *ep.alpha_dev[0];
+  if (ep.alpha_dev[1]) a *= *ep.alpha_dev[1];
+  return a;
+}
+
+// epilogue for one output element; returns the stored value (BN statistics use it).  alpha = ep_alpha(ep), taken once by the caller
+__device__ __forceinline__ float finalize_store(const GemmEpilogue& ep, int m, int n, float v, float alpha) {
+  v *= alpha;
   if (ep.bias) v += ep.bias[n];
   if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
   else if (ep.act == ACT_SIGMOID) v = sigmoidf_(v);
@@ -40,7 +48,7 @@ __device__ __forceinline__ void gemm_epilogue(const P& p, f32x16 (&acc)[BM / 64]
   // and dominated the short-K launches (K = 64: 137 us with it, 40 us without any epilogue).
   const bool fast = p.splitk == 1 && !p.ep.row_map && !p.ep.C2 && p.ep.act == ACT_NONE &&
                     (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
-  const float alpha = p.ep.alpha;       // (1 except for the f16x2 operand format: a power of two, exact)
+  const float alpha = ep_alpha(p.ep);   // (1 except for the f16x2 operand format: a power of two, exact)
   if (fast) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -79,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const P& p, f32x16 (&acc)[BM / 64]
           if (p.splitk > 1) {
             p.ws[((long long)z * p.M + m) * p.N + n] = acc[i][j][r];
           } else {
-            const float v = finalize_store(p.ep, m, n, acc[i][j][r]);
+            const float v = finalize_store(p.ep, m, n, acc[i][j][r], alpha);
             cs[j] += v;
             cs2[j] += v * v;
           }

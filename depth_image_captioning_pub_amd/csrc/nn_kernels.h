@@ -12,6 +12,19 @@ struct BnBuf {
   float *scale, *shift, *mean, *invstd;
 };
 
+// A power-of-two scale of the f16x2 operand format that is CHOSEN ON THE DEVICE (trained weights, gradients: their magnitude is not
+// known on the host without a synchronisation).  `bound` receives the bit pattern of an upper bound of |x| (atomicMax of
+// non-negative floats = atomicMax of their bits), pow2_scale turns it into s = 2^(13 - floor(log2 bound)) - bound * s in
+// [2^13, 2^14): fp16's exponent range leaves room for bounds that are loose by several powers of two - and 1 / s; the kernels that
+// split read slot[0], the contraction epilogues read slot[1] through GemmEpilogue::alpha_dev.  All in the caller's workspace.
+struct F16Scale {
+  unsigned* bound;     // device word, zeroed by f16_scale_reset
+  float* slot;         // device {s, 1 / s}
+};
+int f16_scale_reset(unsigned* bounds, int n, hipStream_t st);                       // bounds[0..n) = 0
+int f16_scale_from_absmax(const float* x, long long n, F16Scale s, hipStream_t st); // bound = max |x| (exact), then the slot
+int f16_scale_finish(F16Scale s, hipStream_t st);                                   // slot from a bound other kernels have raised
+
 // train mode: reduce the conv epilogue's per-tile partial sums [mtiles][2][C] (fp64), produce
 // scale/shift (+ saved mean/invstd) and update the running statistics (unbiased variance).
 // `red`: fp64 scratch of bn_finalize_ws_doubles(max mtiles, C) doubles.
@@ -56,13 +69,15 @@ int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hi
 // BatchNorm backward (train mode): dgamma, dbeta and dx (in place over dy). ws: >= 2*64*C + 3*C floats.
 int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
                 float* dbeta, float* ws, hipStream_t st,
-                unsigned short* const dx_planes[3] = nullptr);   /* optional: result also as paired bf16x3 planes */
+                unsigned short* const dx_planes[3] = nullptr   /* optional: result also as paired bf16x3 planes (f16x2 planes when [2] == NULL) */,
+                F16Scale* f16 = nullptr)                        /* f16x2 planes: the device-resident scale slot this call fills and uses */;
 // max-pool (non-overlapping k x k) + ReLU + BatchNorm backward in two passes over x, without materialising the pooled
 // gradient (replaces maxpool_relu_bwd + bn_backward); dy receives the gradient w.r.t. the convolution output
 int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
                      const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st,
-                     unsigned short* const dy_planes[3] = nullptr)   /* optional: dy also as paired bf16x3 planes */;
-size_t bn_backward_ws_floats(int C);
+                     unsigned short* const dy_planes[3] = nullptr   /* optional: dy also as paired bf16x3 planes (f16x2 when [2] == NULL) */,
+                     F16Scale* f16 = nullptr)                        /* f16x2 planes: the device-resident scale slot this call fills and uses */;
+size_t bn_backward_ws_floats(int C);      // (includes the per-block |g| maxima of the f16x2 scale bound)
 // diagnostic: out[r*C + c] = 1 where relu_mask_bwd keeps the gradient (BN output > 0), else 0
 int relu_mask_export(const float* x, long long rows, int C, BnBuf bn, unsigned char* out, hipStream_t st);
 // column sums (bias gradients): out[c] = sum_r X[r*ld + c]

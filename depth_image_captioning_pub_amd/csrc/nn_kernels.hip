@@ -579,13 +579,60 @@ int relu_mask_bwd(float* dy, const float* x, long long rows, int C, BnBuf bn, hi
   return DIC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// device-resident f16x2 scales (F16Scale, nn_kernels.h)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) f16_scale_reset_kernel(unsigned* __restrict__ bounds, int n) {
+  if ((int)threadIdx.x < n) bounds[threadIdx.x] = 0u;
+}
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long long n4, unsigned* __restrict__ bound) {
+  __shared__ float sm[4];
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w) m = __uint_as_float(0x7f800000u);      // a NaN must not hide behind fmaxf
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(bound, __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));      // one atomic per block
+}
+// s = 2^(13 - e), e = floor(log2 bound) clamped to [-60, 60] (a zero tensor gets 2^73: its planes are zeros whatever the scale)
+__global__ void __launch_bounds__(64) f16_scale_finish_kernel(const unsigned* __restrict__ bound, float* __restrict__ slot) {
+  if (threadIdx.x != 0) return;
+  const int e = min(60, max(-60, (int)((*bound >> 23) & 0xffu) - 127));
+  slot[0] = __uint_as_float((unsigned)(13 - e + 127) << 23);
+  slot[1] = __uint_as_float((unsigned)(e - 13 + 127) << 23);
+}
+int f16_scale_reset(unsigned* bounds, int n, hipStream_t st) {
+  DIC_REQUIRE(n <= 64, "f16_scale_reset: at most 64 words");
+  hipLaunchKernelGGL(f16_scale_reset_kernel, dim3(1), dim3(64), 0, st, bounds, n);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+int f16_scale_finish(F16Scale sl, hipStream_t st) {
+  hipLaunchKernelGGL(f16_scale_finish_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)sl.bound, sl.slot);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+int f16_scale_from_absmax(const float* x, long long n, F16Scale sl, hipStream_t st) {
+  DIC_REQUIRE(n % 4 == 0, "f16_scale_from_absmax: n %% 4");
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long long>((n / 4 + 255) / 256, 128)), dim3(256), 0, st, x, n / 4, sl.bound);
+  DIC_LAUNCH_CHECK();
+  return f16_scale_finish(sl, st);
+}
+
 // BatchNorm backward, stage 1: per (row-chunk, channel) sums of dy and dy*xhat.
 // block = 64 channels (16 float4 lanes) x 16 row lanes; grid (C/64, chunks) with enough row chunks for >= 512 blocks
 constexpr int kBnChunksMax = 256;
 static inline int reduce_chunks(int C) { return std::min(kBnChunksMax, std::max(64, 1024 / std::max(1, C / 64))); }
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             long long rows, int C, BnBuf bn, float* __restrict__ part) {
+                                                             long long rows, int C, BnBuf bn, float* __restrict__ part,
+                                                             float* __restrict__ gmaxp) {
   __shared__ float4 sa[16][16], sb[16][16];
+  __shared__ float smax[4];
+  float gm = 0.f;                        // max |dy| over this block's elements (f16x2 scale bound, nullable)
   const int c4l = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4l * 4;
   const long long per = (rows + gridDim.y - 1) / gridDim.y;
@@ -609,11 +656,14 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
         a.x += g[u].x; a.y += g[u].y; a.z += g[u].z; a.w += g[u].w;
         b.x += g[u].x * (v[u].x - mu.x) * is.x; b.y += g[u].y * (v[u].y - mu.y) * is.y;
         b.z += g[u].z * (v[u].z - mu.z) * is.z; b.w += g[u].w * (v[u].w - mu.w) * is.w;
+        gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g[u].x), fabsf(g[u].y))), fmaxf(fabsf(g[u].z), fabsf(g[u].w)));
       }
     }
   }
   sa[rl][c4l] = a; sb[rl][c4l] = b;
+  if (gmaxp) { gm = wave_max(gm); if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gm; }
   __syncthreads();
+  if (gmaxp && threadIdx.x == 0) gmaxp[(long long)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
   if (rl == 0 && c < C) {
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
@@ -628,19 +678,41 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int chunks, int C,
                                                                double rows, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ k2,
-                                                               float* __restrict__ k3) {
+                                                               float* __restrict__ k3, const float* __restrict__ gmaxp,
+                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                               unsigned* __restrict__ bound) {
+  __shared__ float smax[4];
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
+  float bnd = 0.f;
+  if (c < C) {
+    double a = 0.0, b = 0.0;
 #pragma unroll 8
-  for (int t = 0; t < chunks; ++t) {
-    a += (double)part[((long long)t * 2 + 0) * C + c];
-    b += (double)part[((long long)t * 2 + 1) * C + c];
+    for (int t = 0; t < chunks; ++t) {
+      a += (double)part[((long long)t * 2 + 0) * C + c];
+      b += (double)part[((long long)t * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+    k2[c] = (float)(a / rows);
+    k3[c] = (float)(b / rows);
+    if (bound) {
+      // f16x2 scale of the gradient this backward produces (the apply kernel splits it in the same pass that forms it, so its
+      // magnitude has to be bounded beforehand):  dx = gamma * invstd * (g - k2 - xhat * k3),  |xhat| <= sqrt(rows - 1)
+      //   =>  |dx| <= |gamma * invstd| * (max |g| + |k2| + sqrt(rows) * |k3|),   max |g| over this channel's 64-channel block.
+      // Loose by the xhat bound only (a few powers of two), which the fp16 exponent range absorbs (F16Scale, nn_kernels.h).
+      float gm = 0.f;
+      const int cb = c >> 6, ncb = C >> 6;
+      for (int t = 0; t < chunks; ++t) gm = fmaxf(gm, gmaxp[(long long)t * ncb + cb]);
+      bnd = fabsf(gamma[c] * invstd[c]) * (gm + fabsf((float)(a / rows)) + sqrtf((float)rows) * fabsf((float)(b / rows)));
+      if (bnd != bnd) bnd = __uint_as_float(0x7f800000u);
+    }
   }
-  dbeta[c] = (float)a;
-  dgamma[c] = (float)b;
-  k2[c] = (float)(a / rows);
-  k3[c] = (float)(b / rows);
+  if (bound) {
+    bnd = wave_max(bnd);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = bnd;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(bound, __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
+  }
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ x,
@@ -649,8 +721,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ d
                                                             const float* __restrict__ k3,
                                                             unsigned short* __restrict__ hi,
                                                             unsigned short* __restrict__ mid,
-                                                            unsigned short* __restrict__ lo) {
+                                                            unsigned short* __restrict__ lo, const float* __restrict__ f16_slot) {
   const long long stride = (long long)gridDim.x * 256;
+  const float fs = f16_slot ? f16_slot[0] : 1.f;      // f16x2 planes (lo == NULL): the device-resident scale of this gradient
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c = (int)(i % C4) * 4;
     const float4 g = reinterpret_cast<float4*>(dy)[i];
@@ -669,31 +742,39 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ d
     if (hi) {     // the same gradient as paired bf16x3 planes (operand of the data-gradient convolution)
       const long long off = plane_offset(i / C4, c, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
-      split3_bf16(o.x, h[0], m[0], l[0]); split3_bf16(o.y, h[1], m[1], l[1]);
-      split3_bf16(o.z, h[2], m[2], l[2]); split3_bf16(o.w, h[3], m[3], l[3]);
+      if (!lo) {      // f16x2 format: two fp16 planes of fs * o
+        split2_f16(o.x, fs, h[0], m[0]); split2_f16(o.y, fs, h[1], m[1]); split2_f16(o.z, fs, h[2], m[2]); split2_f16(o.w, fs, h[3], m[3]);
+      } else {
+        split3_bf16(o.x, h[0], m[0], l[0]); split3_bf16(o.y, h[1], m[1], l[1]);
+        split3_bf16(o.z, h[2], m[2], l[2]); split3_bf16(o.w, h[3], m[3], l[3]);
+      }
       *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
       *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-      *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+      if (lo) *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
     }
   }
 }
 
-size_t bn_backward_ws_floats(int C) { return (size_t)kBnChunksMax * 2 * C + 2 * (size_t)C; }
+size_t bn_backward_ws_floats(int C) { return (size_t)kBnChunksMax * 2 * C + 2 * (size_t)C + (size_t)kBnChunksMax * (C / 64 + 1); }
 
 int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float* gamma, BnBuf bn, float* dgamma,
-                float* dbeta, float* ws, hipStream_t st, unsigned short* const dx_planes[3]) {
+                float* dbeta, float* ws, hipStream_t st, unsigned short* const dx_planes[3], F16Scale* f16) {
   DIC_REQUIRE(C % 64 == 0, "bn_backward: C %% 64");
+  const bool f16x2 = dx_planes && !dx_planes[2];
+  DIC_REQUIRE(!f16x2 || (f16 && f16->bound && f16->slot), "bn_backward: f16x2 planes need a scale slot");
   float* part = ws;
   float* k2 = ws + (size_t)kBnChunksMax * 2 * C;
   float* k3 = k2 + C;
+  float* gmaxp = k3 + C;
   const int chunks = reduce_chunks(C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C / 64, chunks), dim3(256), 0, st, dy_dx, x, rows, C, bn, part);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C / 64, chunks), dim3(256), 0, st, dy_dx, x, rows, C, bn, part, f16x2 ? gmaxp : nullptr);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, chunks, C, (double)rows,
-                     dgamma, dbeta, k2, k3);
+                     dgamma, dbeta, k2, k3, (const float*)gmaxp, gamma, (const float*)bn.invstd, f16x2 ? f16->bound : nullptr);
+  if (f16x2) DIC_TRY(f16_scale_finish(*f16, st));
   const long long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy_dx, x, n4, C / 4, gamma, bn, k2, k3,
                      dx_planes ? dx_planes[0] : nullptr, dx_planes ? dx_planes[1] : nullptr,
-                     dx_planes ? dx_planes[2] : nullptr);
+                     dx_planes ? dx_planes[2] : nullptr, f16x2 ? (const float*)f16->slot : nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -732,8 +813,11 @@ __device__ __forceinline__ float4 pool_relu_grad4(const float* __restrict__ dpoo
 __global__ void __launch_bounds__(256) bn_pool_bwd_reduce_kernel(const float* __restrict__ dpool,
                                                                   const unsigned char* __restrict__ idx,
                                                                   const float* __restrict__ x, long long rows, int C,
-                                                                  PoolGeom pg, BnBuf bn, float* __restrict__ part) {
+                                                                  PoolGeom pg, BnBuf bn, float* __restrict__ part,
+                                                                  float* __restrict__ gmaxp) {
   __shared__ float4 sa[16][16], sb[16][16];
+  __shared__ float smax[4];
+  float gm = 0.f;                        // max |g| over this block's elements (f16x2 scale bound, nullable)
   const int c4l = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4l * 4;
   const long long per = (rows + gridDim.y - 1) / gridDim.y;
@@ -756,12 +840,15 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_reduce_kernel(const float* __
           a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
           b.x += g.x * (v[u].x - mu.x) * is.x; b.y += g.y * (v[u].y - mu.y) * is.y;
           b.z += g.z * (v[u].z - mu.z) * is.z; b.w += g.w * (v[u].w - mu.w) * is.w;
+          gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
         }
       }
     }
   }
   sa[rl][c4l] = a; sb[rl][c4l] = b;
+  if (gmaxp) { gm = wave_max(gm); if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gm; }
   __syncthreads();
+  if (gmaxp && threadIdx.x == 0) gmaxp[(long long)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
   if (rl == 0 && c < C) {
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
@@ -782,8 +869,9 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
                                                                  const float* __restrict__ k3,
                                                                  unsigned short* __restrict__ hi,
                                                                  unsigned short* __restrict__ mid,
-                                                                 unsigned short* __restrict__ lo) {
+                                                                 unsigned short* __restrict__ lo, const float* __restrict__ f16_slot) {
   const long long stride = (long long)gridDim.x * 256;
+  const float fs = f16_slot ? f16_slot[0] : 1.f;      // f16x2 planes (lo == NULL): the device-resident scale of this gradient
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % C4), c = c4 * 4;
     const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -804,33 +892,41 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
     if (hi) {     // the same gradient as paired bf16x3 planes (operand of the data-gradient convolution)
       const long long off = plane_offset(i / C4, c, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
-      split3_bf16(o.x, h[0], m[0], l[0]); split3_bf16(o.y, h[1], m[1], l[1]);
-      split3_bf16(o.z, h[2], m[2], l[2]); split3_bf16(o.w, h[3], m[3], l[3]);
+      if (!lo) {      // f16x2 format: two fp16 planes of fs * o
+        split2_f16(o.x, fs, h[0], m[0]); split2_f16(o.y, fs, h[1], m[1]); split2_f16(o.z, fs, h[2], m[2]); split2_f16(o.w, fs, h[3], m[3]);
+      } else {
+        split3_bf16(o.x, h[0], m[0], l[0]); split3_bf16(o.y, h[1], m[1], l[1]);
+        split3_bf16(o.z, h[2], m[2], l[2]); split3_bf16(o.w, h[3], m[3], l[3]);
+      }
       *reinterpret_cast<uint2*>(hi + off) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
       *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-      *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+      if (lo) *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
     }
   }
 }
 
 int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
                      const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st,
-                     unsigned short* const dy_planes[3]) {
+                     unsigned short* const dy_planes[3], F16Scale* f16) {
   DIC_REQUIRE(C % 64 == 0, "bn_pool_backward: C %% 64");
+  const bool f16x2 = dy_planes && !dy_planes[2];
+  DIC_REQUIRE(!f16x2 || (f16 && f16->bound && f16->slot), "bn_pool_backward: f16x2 planes need a scale slot");
   const long long rows = (long long)B * H * W;
   const PoolGeom pg{H, W, k, H / k, W / k};
   float* part = ws;
   float* k2 = ws + (size_t)kBnChunksMax * 2 * C;
   float* k3 = k2 + C;
+  float* gmaxp = k3 + C;
   const int chunks = reduce_chunks(C);
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(C / 64, chunks), dim3(256), 0, st, dpool, idx, x, rows, C, pg, bn,
-                     part);
+                     part, f16x2 ? gmaxp : nullptr);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, chunks, C, (double)rows,
-                     dgamma, dbeta, k2, k3);
+                     dgamma, dbeta, k2, k3, (const float*)gmaxp, gamma, (const float*)bn.invstd, f16x2 ? f16->bound : nullptr);
+  if (f16x2) DIC_TRY(f16_scale_finish(*f16, st));
   const long long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dpool, idx, x, dy, n4, C / 4, pg,
                      gamma, bn, k2, k3, dy_planes ? dy_planes[0] : nullptr, dy_planes ? dy_planes[1] : nullptr,
-                     dy_planes ? dy_planes[2] : nullptr);
+                     dy_planes ? dy_planes[2] : nullptr, f16x2 ? (const float*)f16->slot : nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

@@ -465,6 +465,7 @@ class CaptionTrainer:
                                                        workspace=self.enc_ws, compact=compact)   # :204-206
             self.enc_ws = dtape.workspace
             self.depth_fwd_count += 1
+            self.guard.bitwise_or_(native.depth_status_word(dtape))      # the depth encoder's own guard word joins the step's (one 4-byte op)
         self._mark("depth_encoder_fwd")
         if drop_mult is None and self.p_drop > 0:
             drop_mult = native.dropout_mask((B, tmax, native.D_HID), self.p_drop, self.drop_seed, self.rng_offset,

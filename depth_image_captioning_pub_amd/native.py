@@ -322,6 +322,12 @@ def depth_encoder_forward(weights: Dict[str, torch.Tensor], state: Dict[str, tor
     return out, DepthTape(workspace, d, {k: t for (k, _), t in zip(DEPTH_FIELDS, keep)}, compact)
 
 
+def depth_status_word(tape: DepthTape) -> torch.Tensor:
+    """int32[1] device view of the depth encoder's f16x2 overflow guard word (first 4 bytes of its workspace, include/dic.h): non-zero
+    after a forward whose pooled activations left the fp16 range of the operand planes; the features were then filled with NaN."""
+    return tape.workspace[:4].view(torch.int32)
+
+
 def depth_encoder_backward(tape: DepthTape, d_features: torch.Tensor, grads: Optional[Dict[str, torch.Tensor]] = None):
     lib = _lib.load()
     if grads is None:

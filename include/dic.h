@@ -217,6 +217,13 @@ typedef struct dic_depth_bn_state {                 /* running_mean / running_va
   float *rm1, *rv1, *rm2, *rv2, *rm3, *rv3;
 } dic_depth_bn_state;
 
+/* Arithmetic (round 4): conv1 in plain fp32 vector FMAs; conv2 / conv3 - forward, data gradient, weight gradient - in the f16x2 operand
+ * format of the split-operand kernels (two fp16 planes per operand, three matrix-core products, fp32 accumulation: fp32-level results,
+ * tests/test_encoders_gpu.py).  The planes' power-of-two scales: activations 4 (|x| <= 16376 - the first 4 bytes of `workspace` are
+ * the same overflow status word as in dic_resnet_fwd, and `features` are filled with NaN when it is raised), the trained weights and
+ * the gradients a scale chosen ON THE DEVICE every step (exact maximum / a bound computed by the BatchNorm backward), undone by the
+ * contraction epilogues from device memory: no host synchronisation, no range assumption on weights or gradients.
+ * dic_debug_force_staged_gemm(116) selects the exact three-way bf16 split of rounds 1-3 instead (117: back to the default). */
 size_t dic_depth_encoder_workspace_bytes(int B, int H, int W);
 /* forward (depth_models.py:49-56): depth [B,1,H,W] -> features [B,196,2048]; train=1 uses batch
  * statistics and updates the running stats, train=0 uses the running stats. */

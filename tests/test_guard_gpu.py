@@ -186,3 +186,33 @@ def test_dpt_runner_guard_word(lib):
         bad.forward(x)
     assert int(bad.overflow.item()) != 0
     assert torch.isfinite(dpt.DptRunner(w2, cfg, arith="bf16x3").forward(x)).all()
+
+
+def test_depth_encoder_guard_word(lib):
+    """The depth encoder's conv2 / conv3 read f16x2 planes of 4 * (pooled BatchNorm output): a BatchNorm gain that pushes it beyond
+    16376 raises the status word at offset 0 of its workspace and turns the features into NaN; the engine ORs that word into the
+    step's guard (AdamW skipped on the device, DicError from check_status)."""
+    enc, st = syn.depth_encoder_weights(seed=124)
+    enc = {k: v.to(DEV) for k, v in enc.items()}
+    st = {k: v.to(DEV) for k, v in st.items()}
+    depth = syn.depth_maps(4, seed=9).to(DEV)
+    f, tape = native.depth_encoder_forward(enc, st, depth, train=True, compact=True)
+    assert torch.isfinite(f).all() and int(native.depth_status_word(tape).item()) == 0
+    enc["bn1.weight"].fill_(1.0e5)
+    f, tape = native.depth_encoder_forward(enc, st, depth, train=True, compact=True)
+    torch.cuda.synchronize()
+    assert int(native.depth_status_word(tape).item()) != 0 and bool(torch.isnan(f).all())
+    # through the engine
+    vocab = 60
+    tr = CaptionTrainer(vocab, device=DEV, resnet_layers=TINY, seed=2)
+    imgs = syn.rgb_images(4, seed=70, size=224).to(DEV)
+    caps, lens = syn.captions_fixed(4, vocab, 6, seed=70)
+    tr.train_step(imgs, depth, caps.to(DEV), lens)
+    tr.check_status()
+    snap = tr.flat.data.clone()
+    tr.enc_w["bn1.weight"].fill_(1.0e5)
+    snap = tr.flat.data.clone()
+    tr.train_step(imgs, depth, caps.to(DEV), lens)
+    with pytest.raises(DicError, match="overflow guard"):
+        tr.check_status()
+    assert torch.equal(tr.flat.data, snap), "parameters changed although the update had to be skipped"
