@@ -89,6 +89,9 @@ size_t gemm_splitk_ws_bytes(int M, int N, int splitk);
 constexpr size_t kGemmTailWsBytes = (size_t)256 * 64 * 64 * sizeof(float);   // tail_ws capacity needed by gemm_launch
 int gemm_pick_tile(int M, int N);               // 128 or 64
 int gemm_launch(GemmParams p, hipStream_t st, int force_tile = 0);
+constexpr int kGemmGroupMax = 6;
+// several independent K-major x K-major contractions (64x64 tiles) in one launch; ps[i] is completed in place (gemm.hip)
+int gemm_launch_group_colk(GemmParams* ps, int n, hipStream_t st);
 GemmOperand op_rowk(const float* p, long long ld);
 GemmOperand op_colk(const float* p, long long ld);
 GemmOperand op_im2col(const float* x, const ConvGeom& g);

@@ -607,8 +607,10 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
   }
 }
 
+// One output tile (or K slice of one) of a contraction: the body of gemm_kernel, also run by gemm_group_kernel over several problems.
+// bid / nblk: this workgroup's index among the problem's nblk workgroups.
 template <int BM, int BN, int AK, int BKIND, int ABL = 0>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_tile_body(const GemmParams& p, const int bid, const int nblk) {
   using LA = Loader<AK, BM>;
   using LB = Loader<BKIND, BN>;
   constexpr int LDA = LA::LD, LDB = LB::LD;
@@ -618,7 +620,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int lb = xcd_remap(bid, nblk);
   const int tiles = p.mtiles * p.ntiles;
   const int z = lb / tiles, t = lb - z * tiles;
   const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
@@ -713,14 +715,46 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   gemm_epilogue<BM, BN>(p, acc, tm, tn, z, As[0]);
 }
 
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) {
+template <int BM, int BN, int AK, int BKIND, int ABL = 0>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
+  gemm_tile_body<BM, BN, AK, BKIND, ABL>(p, blockIdx.x, gridDim.x);
+}
+
+// Several INDEPENDENT contractions of one operand-kind pair in one launch: workgroup b belongs to problem i with
+// first[i] <= b < first[i + 1].  For the batches of small products that follow a dependent chain (the decoder's weight gradients after
+// BPTT: five launches of 5-70 us, each with its own launch boundary, partly filled grid and tail) - one grid, one tail.
+struct GemmGroup {
+  int n;
+  int first[kGemmGroupMax + 1];
+  GemmParams p[kGemmGroupMax];
+};
+static_assert(sizeof(GemmGroup) <= 4096, "GemmGroup travels as a kernel argument");
+template <int BM, int BN, int AK, int BKIND>
+__global__ void __launch_bounds__(256) gemm_group_kernel(const GemmGroup g) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kGemmGroupMax; ++j)
+    if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
+  gemm_tile_body<BM, BN, AK, BKIND>(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);
+}
+
+__device__ __forceinline__ void splitk_reduce_body(const GemmParams& p, const int bid, const int nblk) {
   const long long total = (long long)p.M * p.N;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+  const float alpha = ep_alpha(p.ep);
+  for (long long e = (long long)bid * 256 + threadIdx.x; e < total; e += (long long)nblk * 256) {
     float s = 0.f;
     for (int z = 0; z < p.splitk; ++z) s += p.ws[(long long)z * total + e];
     const int m = (int)(e / p.N), n = (int)(e - (long long)m * p.N);
-    finalize_store(p.ep, m, n, s, ep_alpha(p.ep));
+    finalize_store(p.ep, m, n, s, alpha);
   }
+}
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmParams p) { splitk_reduce_body(p, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) splitk_reduce_group_kernel(const GemmGroup g) {      // first[] counts reduce workgroups here
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kGemmGroupMax; ++j)
+    if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
+  splitk_reduce_body(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -989,6 +1023,60 @@ int gemm_launch(GemmParams p, hipStream_t st, int force_tile) {
     const long long total = (long long)p.M * p.N;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    DIC_LAUNCH_CHECK();
+  }
+  return DIC_OK;
+}
+
+// n <= kGemmGroupMax independent contractions, all with K-major ("colk") A and B operands and 64x64 tiles, in ONE launch (+ one
+// launch that reduces the split-K slabs of those that asked for a K split; each needs its own `ws` region).  Same arithmetic and
+// summation order per problem as gemm_launch(p, st, 64).
+int gemm_launch_group_colk(GemmParams* ps, int n, hipStream_t st) {
+  DIC_REQUIRE(n >= 1 && n <= kGemmGroupMax, "gemm group: 1..%d problems", kGemmGroupMax);
+  GemmGroup g{}, r{};
+  g.n = n;
+  int blocks = 0, rblocks = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    GemmParams& p = ps[i];
+    DIC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.A.p && p.B.p && p.ep.C, "gemm group: bad problem %d", i);
+    DIC_REQUIRE(p.A.kind == OPK_COLK && p.B.kind == OPK_COLK && !p.ep.stats && !p.raw_partials, "gemm group: K-major operands only");
+    p.mtiles = ceil_div(p.M, 64); p.ntiles = ceil_div(p.N, 64);
+    const int nk = ceil_div(p.K, BK);
+    if (p.splitk < 1) p.splitk = 1;
+    if (p.splitk > nk) p.splitk = nk;
+    p.ktiles_per_split = ceil_div(nk, p.splitk);
+    p.splitk = ceil_div(nk, p.ktiles_per_split);
+    DIC_REQUIRE(p.splitk == 1 || p.ws != nullptr, "gemm group: split-K needs a workspace");
+    if (p.ep.alpha == 0.0f) p.ep.alpha = 1.0f;
+    p.tail_first_block = p.mtiles * p.ntiles * p.splitk; p.tail_first_tile = 0; p.tail_split = 1; p.tail_ws = nullptr;
+    g.first[i] = blocks;
+    blocks += p.mtiles * p.ntiles * p.splitk;
+    g.p[i] = p;
+    flops += 2.0 * p.M * p.N * (double)p.K;
+    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+    if (p.splitk > 1) {
+      r.first[r.n] = rblocks;
+      rblocks += (int)std::min<long long>(((long long)p.M * p.N + 255) / 256, 512);
+      r.p[r.n++] = p;
+    }
+  }
+  g.first[n] = blocks;
+  r.first[r.n] = rblocks;
+  ProfRec rec{};
+  if (g_prof_on) {
+    rec.e0 = prof_event(); rec.e1 = prof_event();
+    rec.flops = flops; rec.bytes = bytes; rec.key = OPK_COLK * 10 + OPK_COLK;
+    (void)hipEventRecord(rec.e0, st);
+  }
+  hipLaunchKernelGGL((gemm_group_kernel<64, 64, OPK_COLK, OPK_COLK>), dim3(blocks), dim3(256), 0, st, g);
+  DIC_LAUNCH_CHECK();
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.e1, st);
+    g_prof_recs.push_back(rec);
+  }
+  if (r.n > 0) {
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, st, r);
     DIC_LAUNCH_CHECK();
   }
   return DIC_OK;

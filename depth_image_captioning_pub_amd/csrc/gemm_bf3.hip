@@ -1385,6 +1385,7 @@ static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the 
 static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
+static int g_bf3_wgrad_persist = 1;    // weight gradients with 32..255 output tiles of 128x128: on the persistent kernel, every tile in K slices (codes 118 / 119)
 static int g_bf3_remainder_grid = 256; // ... and the workgroups such a launch may use
 static int g_bf3_ws256 = 1;            // codes 80 / 81: 256x128 form of the warp-specialised kernel for f16x2 row-major plain-epilogue launches by policy (default) / never
 static int g_bf3_slots = 4;            // codes 114 / 115: input slots in flight per producer wave of the eight-producer form: 4 (default) / 6
@@ -1395,6 +1396,7 @@ static int g_bf3_producers = 8;        // codes 112 / 113: producer waves of the
 static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_ablate = 0;           // 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
+static int g_bf3_bn_ablate = 0;        // on-the-fly-operand kernel, timing only (wrong results): bit 0 = no residual read, bit 1 = no fp32 copy written (57..59)
 #else
 constexpr int g_bf3_stages = 2, g_bf3_ws = 1, g_bf3_ablate = 0;
 #endif
@@ -1430,14 +1432,16 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 90 || code == 91) { g_bf3_remainder_split = code - 90; return 0; }      // remainder-round K split of the persistent kernels off / on (default)
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
   if (code == 112 || code == 113) { g_bf3_producers = code == 112 ? 4 : 8; return 0; }      // f16x2 on-the-fly-operand kernel: four / eight (default) producer waves
-  if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }          // ... its input slots in flight per producer wave: four (default) / six
+  if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }
+  if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)          // ... its input slots in flight per producer wave: four (default) / six
 #ifdef DIC_EXPERIMENTS
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
   if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
   if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
-  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
+  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; if (code == 50) g_bf3_bn_ablate = 0; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
+  if (code >= 57 && code <= 59) { g_bf3_bn_ablate = code - 56; return 0; }       // (50 clears it)
   if (code == 77) { g_bf3_ws = 0; return 0; }
   if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
 #endif
@@ -1607,6 +1611,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     g_last_mtiles = 2 * p.mtiles;          // statistics rows per 64-row wave tile
     // as few workgroups as give the same number of tiles per workgroup: the CUs left over serve the other stream's kernels
     const int grid = persist_grid;
+#ifdef DIC_EXPERIMENTS
+    if (p.a_raw && (g_bf3_bn_ablate & 1)) p.a_res = nullptr;
+    if (p.a_raw && (g_bf3_bn_ablate & 2)) p.a_out = nullptr;
+#endif
     if (p.fmt == 1) {
       if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8>), dim3(grid), dim3(768), 0, st, p);
@@ -1861,8 +1869,18 @@ size_t conv_wgrad_bf3_plane_elems(const ConvDesc& d, int which) {     // which: 
   const size_t rows = which == 0 ? (size_t)d.CO : (size_t)d.K();
   return ((rows + 1) & ~(size_t)1) * kpad;
 }
+// Few-tiles route of the weight gradient (round 4): dW is CO x K() with a very long contraction (every output pixel of the batch), e.g.
+// 512 x 1152 over 30 976 for the depth encoder's conv2 - 36 tiles of 128 x 128.  launch_bf3's "few tiles, long K" form cuts every tile
+// into K slices, one per workgroup of the persistent warp-specialised kernel, and the tail fix-up sums them in K order (deterministic):
+// measured 190 -> ... us for conv2 against the 64 x 64 tiles with the caller's K split (720 workgroups of one computing wave per SIMD).
+static bool wgrad_persist_shape(const ConvDesc& d) {
+  const long long t22 = (long long)ceil_div(d.CO, 128) * ceil_div(d.K(), 128);
+  return d.K() % 128 == 0 && t22 >= 32 && t22 < g_bf3_remainder_grid && (d.M() + 31) / 32 >= 64;
+}
 size_t conv_wgrad_bf3_ws_floats(const ConvDesc& d, int splitk) {
-  return (size_t)ceil_div(d.CO, 64) * ceil_div(d.K(), 64) * splitk * 64 * 64;
+  size_t n = (size_t)ceil_div(d.CO, 64) * ceil_div(d.K(), 64) * splitk * 64 * 64;
+  if (wgrad_persist_shape(d)) n = std::max(n, (size_t)4 * g_bf3_remainder_grid * 64 * 64);      // four [64][64] slabs per slice, <= one slice per CU
+  return n;
 }
 
 int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw_ohwi, int splitk,
@@ -1885,6 +1903,8 @@ int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw
   p.B.kind = OPK_ROWK; p.B.ld = Kpad; p.B.paired = 1;
   p.ep = ep_store(dw_ohwi, d.K(), nullptr, ACT_NONE);
   if (fmt) { p.fmt = 1; p.ep.alpha = 1.0f / kF16ActScale; p.ep.alpha_dev[0] = dy_slot + 1; }      // 1 / (s_dy * 4): the first factor lives on the device
+  if (g_bf3_wgrad_persist && wgrad_persist_shape(d))
+    return launch_bf3(p, st, ws, 1, nullptr, nullptr, nullptr, 4 * g_bf3_remainder_grid);
   return launch_bf3(p, st, nullptr, splitk, ws);
 }
 

@@ -427,6 +427,9 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *                format (default: both in mode 1, block outputs only in mode 2)
  *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
  *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
+ *   116 117      depth encoder conv2 / conv3 (forward and both gradients): exact bf16x3 split / f16x2 with device-resident scales (default)
+ *   118 119      weight gradients whose output is 32..255 tiles of 128x128 (the depth encoder's two): 64x64 tiles with the caller's K
+ *                split / persistent warp-specialised kernel with every tile cut into K slices (default)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
  * 256x128 contraction forms, the A-stationary conv3 kernel of round 4, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes

