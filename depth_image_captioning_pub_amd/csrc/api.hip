@@ -4,7 +4,7 @@
 
 using namespace dic;
 
-namespace dic { void resnet_fuse_bn_operand(int mask); void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n);
+namespace dic { void resnet_fuse_bn_operand(int mask); void resnet_fuse_bn_halo(int on); void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n);
                 void depth_encoder_f16x2(int on); }
 #ifdef DIC_EXPERIMENTS
 namespace dic { void decoder_debug_persistent(int on); void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p);
@@ -57,6 +57,7 @@ int dic_conv2d_fwd(const float* x, int B, int H, int W, int C, int in_nchw, cons
 int dic_debug_force_staged_gemm(int on) {
   if (gemm_bf3_force_tile(on) == 0) return 0;
   if (on >= 100 && on <= 104) { dic::resnet_fuse_bn_operand(on == 104 ? -1 : on - 100); return 0; }
+  if (on == 108 || on == 109) { dic::resnet_fuse_bn_halo(on - 108); return 0; }       // conv1 -> conv2 BatchNorm-apply inside the halo kernel: never / by shape (default)
   if (on == 116 || on == 117) { dic::depth_encoder_f16x2(on - 116); return 0; }      // depth encoder conv2 / conv3: bf16x3 / f16x2 (default)
 #ifdef DIC_EXPERIMENTS
   if (on == 140 || on == 141) { dic::decoder_debug_persistent(on - 140); return 0; }          // decoder forward: per-step launches / persistent loop
@@ -107,6 +108,15 @@ int dic_debug_conv1x1_bn_fmt(const float* raw, const float* scale, const float* 
                              int tail_ws_slabs, int fmt, float out_scale, void* stream) {
   return conv1x1_fwd_bf3_bn(raw, scale, shift, res, relu, act_out, M, C, w_planes, CO, y, bn_partial, mtiles_out, tail_ws, tail_ws_slabs,
                             (hipStream_t)stream, nullptr, nullptr, fmt, out_scale);
+}
+/* development aid (not in dic.h): the 3x3 / stride 1 / pad 1 convolution of 14x14 maps with the BatchNorm-apply + ReLU + f16x2 split of its
+ * input done inside the LDS-halo kernel (conv3x3_fwd_bf3_bn, gemm_bf3.hip); returns 1 when that kernel does not take the shape */
+int dic_debug_conv3x3_bn(const float* raw, const float* scale, const float* shift, int relu, int B, int H, int W, int C,
+                         const uint16_t* const w_planes[3], int CO, float* y, float* bn_partial, int* mtiles_out, float* tail_ws,
+                         int tail_ws_slabs, float out_scale, uint32_t* status, void* stream) {
+  ConvDesc d{B, H, W, C, CO, 3, 3, 1, 1, 0};
+  return conv3x3_fwd_bf3_bn(raw, scale, shift, relu, d, w_planes, y, bn_partial, mtiles_out, tail_ws, tail_ws_slabs, (hipStream_t)stream,
+                            nullptr, nullptr, 1, out_scale, status);
 }
 #ifdef DIC_EXPERIMENTS
 /* development aid (not in dic.h): the A-stationary conv3 kernel alone (conv1x1_astat_bn, gemm_bf3.hip): y = relu(raw * scale + shift) . W^T

@@ -40,6 +40,11 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
                        int* bn_fused = nullptr, int fmt = 0, float out_scale = 1.0f,
                        unsigned* status = nullptr /* f16x2: overflow guard word (common.h) */);
 bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs);
+// 3x3 / stride 1 / pad 1 convolution of 14x14 maps with the same fusion, in the LDS-halo kernel's producer waves (f16x2 format only);
+// returns 1 (nothing launched) for every other shape / format
+int conv3x3_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, int relu, const ConvDesc& d,
+                       const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, float* tail_ws,
+                       int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused, int fmt, float out_scale, unsigned* status);
 // (parked, experiments build: the same operation for SHORT contractions on the A-stationary kernel - csrc/experiments/conv1x1_astat.inc)
 #ifdef DIC_EXPERIMENTS
 bool conv1x1_astat_eligible(int M, int C, int CO);

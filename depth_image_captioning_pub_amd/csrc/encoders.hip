@@ -296,6 +296,27 @@ static int conv_bn_bf3_astat(const float* raw, const BnBuf& in_bn, const ConvDes
 static int g_fuse_bn_operand_switch = -1;      // -1 (code 104, default): by operand format - both for bf16x3; block outputs only for f16x2, where the
                                                // matrix-core work per K tile is halved and conv3's eightfold re-transform of its input no longer hides
 void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand_switch = mask < 0 ? -1 : (mask & 3); }
+static int g_fuse_bn_halo = 1;                 // codes 108 / 109: conv1's output (consumed by the 3x3 conv2) formed inside the LDS-halo kernel's producer waves: never / where
+                                               // that kernel takes the shape (default; f16x2 format, 14x14 maps: 35 of ResNet-152's 50 blocks)
+void resnet_fuse_bn_halo(int on) { g_fuse_bn_halo = on; }
+
+// conv2 (3x3, stride 1, 14x14 maps) whose input relu(bn1(raw1)) is formed inside the LDS-halo kernel (conv3x3_fwd_bf3_bn, gemm_bf3.hip) ->
+// raw fp32 out + BN scale/shift in `bn`.  Returns 1 when that kernel does not take the shape (nothing launched).
+static int conv_bn_bf3_halo_fused(const float* raw, const BnBuf& in_bn, const ConvDesc& d, const dic_conv_bn_layer& L, float* y, const RnWs& ws,
+                                  int train_bn, hipStream_t st, const BnBuf& bn, int fmt) {
+  if (!fmt || !g_fuse_bn_halo) return 1;
+  int mtiles = 0, fused = 0;
+  const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
+  const BnFuseArgs fa{L.gamma, L.beta, L.running_mean, L.running_var, bn.scale, bn.shift, bn.mean, bn.invstd,
+                      (double)d.M(), kBnEps, kBnMomentum, ws.status};
+  const int rc = conv3x3_fwd_bf3_bn(raw, in_bn.scale, in_bn.shift, 1, d, wp, y, train_bn ? ws.partial : nullptr, &mtiles, ws.tail, kResnetTailSlabs, st,
+                                    (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, fmt, 1.0f / (kF16ActScale * L.w_scale), ws.status);
+  if (rc != DIC_OK) return rc;
+  if (train_bn && fused) return DIC_OK;
+  if (train_bn)
+    return bn_finalize_train(ws.partial, mtiles, d.M(), d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, ws.red, st, ws.status);
+  return bn_finalize_eval(d.CO, L.gamma, L.beta, L.running_mean, L.running_var, bn, st);
+}
 
 // ResNet forward with the bf16x3 convolution.  A convolution reads either three bf16 planes (written by a bn_apply_planes pass; the 3x3
 // and strided layers need that form) or - the stride-1 1x1 layers on the persistent kernel - the raw fp32 output of the layer before
@@ -362,8 +383,14 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       } else {
         DIC_TRY(conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st, nullptr, fmt));
       }
-      DIC_BN_APPLY_PLANES(R1, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st, nullptr, guard);
-      DIC_TRY(conv_bn_bf3(P1, c2.d, layers[c2.layer], R2, ws, train_bn, st, &ws.bn2, fmt));
+      {
+        int rc = conv_bn_bf3_halo_fused(R1, ws.bn, c2.d, layers[c2.layer], R2, ws, train_bn, st, ws.bn2, fmt);
+        if (rc == 1) {                      // not the halo kernel's shape (or mode): planes of relu(bn1(raw1)) first
+          DIC_BN_APPLY_PLANES(R1, nullptr, nullptr, nullptr, P1, c1.d.M(), c1.d.CO, ws.bn, 1, st, nullptr, guard);
+          rc = conv_bn_bf3(P1, c2.d, layers[c2.layer], R2, ws, train_bn, st, &ws.bn2, fmt);
+        }
+        DIC_TRY(rc);
+      }
       if (b == 0) {
         const RnConv& ds = pl.convs[ci++];
         // downsample branch: raw output + its own statistics; its BatchNorm is applied where the block output is formed

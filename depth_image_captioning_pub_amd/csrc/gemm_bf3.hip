@@ -119,6 +119,7 @@ struct Bf3Params {
   int a_relu;
   int fmt;                      // operand format of A and B: 0 = bf16x3, 1 = f16x2 (ep.alpha then carries 1 / (scale_a * scale_b))
   unsigned* status;             // f16x2 overflow guard word (common.h), nullable: raised by the producer waves of the on-the-fly operand
+  int few_remap;                // few-tiles launches: XCD-aware (tile, slice) assignment (few_tiles_remap)
 };
 constexpr int OPK_ROWK_BN = 6;     // (A-operand kind of the kernel template; never stored in Bf3Operand::kind)
 constexpr int kBnTabMax = 2048;    // channels of the on-the-fly operand (its scale / shift table lives in LDS)
@@ -460,6 +461,31 @@ __global__ void __launch_bounds__(256) gemm_bf3_kernel(const Bf3Params p) {
 #endif
 
 
+// Few-tiles launches (every one of T output tiles cut into sp K slices, G = T * sp workgroups, no whole tiles): which (tile, slice)
+// workgroup b computes, returned as tile * sp + slice.  The plain order - tile = b / sp, slice = b % sp - scatters the workgroups that
+// read the same operand panel over all eight XCDs (the hardware deals workgroup b to XCD b % 8), so every XCD's L2 fetches every
+// panel: the depth encoder's conv2 weight gradient (36 tiles x 7 slices, K = 30 976) fetched 1.05 GB for 206 MB of operands and ran at
+// the memory system's pace (profiles/r04a: 153 us).  Here slice z lives on XCD z: its tiles 0 .. n_z - 1 on that XCD's n_z workgroups,
+// all walking the same K range in step, so each panel of the slice crosses the fabric once; the tiles that do not fit (T > n_z) go to
+// the workgroups left over (XCDs >= sp, and any beyond T on the first sp).  A bijection for every (T, sp <= 7, G = T * sp).
+__device__ __forceinline__ int few_tiles_remap(int b, int T, int sp, int G) {
+  if (sp > 7 || G != T * sp) return b;
+  const int x = b & 7, i = b >> 3;
+  if (x < sp && i < T) return i * sp + x;
+  int rank = 0;                                   // this workgroup's rank among the left-over workgroups, XCD-major
+  for (int xx = 0; xx < 8; ++xx) {
+    const int n = (G - xx + 7) >> 3, first = xx < sp ? min(n, T) : 0;
+    if (xx == x) { rank += i - first; break; }
+    rank += n - first;
+  }
+  for (int z = 0; z < sp; ++z) {                  // the rank-th left-over (slice, tile): slice-major
+    const int f = min((G - z + 7) >> 3, T), cnt = T - f;
+    if (rank < cnt) return (f + rank) * sp + z;
+    rank -= cnt;
+  }
+  return b;
+}
+
 // Warp-specialised form of gemm_bf3_persist_kernel: waves 0..3 only compute (fragment reads, MFMAs, stores), waves 4..7 only
 // move operands (LDS-DMA issue and the counted vmcnt that says a slot has landed); both meet at the one barrier per K tile.
 // Why: with DMA issue inside the computing waves a K tile costs 3500-4000 cycles against 2500-2600 without any DMA
@@ -492,9 +518,10 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
   const int F = split ? p.tail_first_tile : T;
   const int ntl = (F - (int)blockIdx.x + G - 1) / G;
   const int per = split ? (nkt + p.tail_split - 1) / p.tail_split : 0;
-  const bool has_piece = split && (int)blockIdx.x < (T - F) * p.tail_split;
-  const int piece_tile = has_piece ? F + (int)blockIdx.x / p.tail_split : 0;
-  const int pk0 = has_piece ? ((int)blockIdx.x % p.tail_split) * per : 0;
+  const int pb = (split && F == 0 && p.few_remap) ? few_tiles_remap((int)blockIdx.x, T, p.tail_split, G) : (int)blockIdx.x;      // piece index (few-tiles launches: XCD-aware)
+  const bool has_piece = split && pb < (T - F) * p.tail_split;
+  const int piece_tile = has_piece ? F + pb / p.tail_split : 0;
+  const int pk0 = has_piece ? (pb % p.tail_split) * per : 0;
   const int npk = has_piece ? min(nkt, pk0 + per) - pk0 : 0;
   const int nwork = ntl + (has_piece ? 1 : 0);
   const int total = ntl * nkt + npk;
@@ -713,6 +740,8 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
         if (g + 1 < total) {
           if (steady_ok && g >= 2 && g + DA < total) {
             // (waves without the weight DMA - NPW = 8 - only need L(g+1): the DA - 1 younger loads may stay in flight)
+            // (stores of the fp32 copy, tiles that keep it, are younger than the awaited slot and not counted: the wait then covers more, never
+            //  less.  Counting them exactly - round 4, a history bit per transform - changed nothing: 54.0 us inside a ResNet forward either way)
             if (b_wave) { if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NR + 2 * NPL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR + 2 * NPL) : "memory"); }
             else { if (has_res) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * 2 * NR) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * NR) : "memory"); }
           } else {
@@ -837,7 +866,7 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
     const bool full = piece || ((tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N);
     const bool plain = piece || (!p.ep.bias && p.ep.act == ACT_NONE && !p.ep.accumulate);
     const int n0 = piece ? (lane & 31) : tn * BN + wn * 64 + (lane & 31), m0 = piece ? 4 * h : tm * BM + wm * 64 + 4 * h;
-    float* const Cb = piece ? p.tail_ws + ((long long)(((int)blockIdx.x / p.tail_split) * 4 + wave) * p.tail_split + (int)blockIdx.x % p.tail_split) * (64 * 64)
+    float* const Cb = piece ? p.tail_ws + ((long long)((pb / p.tail_split) * 4 + wave) * p.tail_split + pb % p.tail_split) * (64 * 64)
                             : p.ep.C;
     const long long ldc = piece ? 64 : p.ep.ldc;
     float cs[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};
@@ -1094,8 +1123,16 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
 //     per K tile, weights three tiles ahead, the next chunk's halo issued at tap 0 of the current chunk (8 K tiles early);
 //   * summation order per output: chunk-major, tap-minor (the other kernels: tap-major) - same products, fp32-level
 //     differences in the last bit, not bit-identical to them.
-template <int ABL, int FMT = 0>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
+//   * BNA (round 4, f16x2 only): the input is the RAW fp32 output of the convolution before (p.a_raw, [M][C]) and the halo image is
+//     act(raw * scale[c] + shift[c]) formed by the producer waves - the BatchNorm-apply + ReLU + split pass that used to write the
+//     planes (bn_apply_planes: 8 B per element of HBM traffic and a launch) is gone.  Once per 32-channel chunk, i.e. once per nine
+//     K tiles: thread (pixel slot, channel quad) loads 7 x 16 B of the next chunk at tap 0 (complete by tap 2: the counted waits
+//     for the weight tiles issued after them cover them), transforms and writes the two plane images at tap 2, six K tiles before
+//     the computing waves first read them.  Padding pixels are written as zeros (the padding applies to the activation).
+constexpr int kHaloBnTab = 512;       // channels of the on-the-fly operand of the halo kernel (scale | shift table in LDS)
+template <int ABL, int FMT = 0, bool BNA = false>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
 __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p) {
+  static_assert(!BNA || FMT == 1, "on-the-fly halo operand: f16x2 only");
   constexpr int BM = 128, BN = 128, NSTB = 3, HROW = 16, RMAX = 13;
   constexpr int HPLANE = RMAX * HROW * BK3, HBUF = 3 * HPLANE;        // elements: 13 KB per plane, 39 KB per buffer
   constexpr int BPLANE = BN * BK3, BSTAGE = 3 * BPLANE;               // 24 KB per weight tile
@@ -1105,6 +1142,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
   __shared__ __align__(1024) unsigned short smem[2 * HBUF + NSTB * BSTAGE + 512];
   unsigned short* const bring = smem + 2 * HBUF;
   unsigned short* const dummy = smem + 2 * HBUF + NSTB * BSTAGE;
+  __shared__ float halo_bn_tab[BNA ? 2 * kHaloBnTab : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.A.g.H, W = p.A.g.W, C = p.A.g.C, ohw = H * W, nimg = p.M / ohw;
@@ -1123,6 +1161,10 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
   const int nwork = ntl + (has_piece ? 1 : 0);
   const int nchunks = ntl * NC + npc, total = nchunks * 9;
   if (total == 0) return;
+  if constexpr (BNA) {     // scale / shift of every input channel -> LDS (all eight waves; one barrier, once per launch)
+    for (int k = tid; k < C; k += 512) { halo_bn_tab[k] = p.a_scale[k]; halo_bn_tab[kHaloBnTab + k] = p.a_shift[k]; }
+    __syncthreads();
+  }
 
   auto tile_of = [&](int j, int& tm, int& tn) {
     const int t = j < ntl ? xcd_remap(blockIdx.x + j * G, F) : piece_tile;
@@ -1173,6 +1215,93 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     };
+    // ---- on-the-fly operand (BNA): thread (ps, l8) of the 256 producer threads owns channels 4*l8 .. 4*l8+3 of the pixel slots
+    // q = ps + 32*i, i < 7 (13 rows x 16 padded pixels = 208 slots; i = 6 exists for ps < 16 only).  Every thread ALWAYS issues its
+    // seven loads (slots that are padding, beyond the batch or beyond the buffer read element 0 and are replaced by zeros): the
+    // counted waits rely on the instruction count.
+    constexpr int NRAW = 7;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ ra[BNA ? NRAW : 1];
+#pragma unroll
+    for (int i = 0; i < (BNA ? NRAW : 1); ++i) ra[i] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    unsigned roff[BNA ? NRAW : 1], rdst[BNA ? NRAW : 1];
+    unsigned rok = 0u, rcc = 0u;                             // bit i: slot i holds a real pixel; channel chunk of the loads in flight
+    const int pt = tid - 256, l8 = pt & 7, ps = pt >> 3;
+    if constexpr (BNA) {
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) {
+        const unsigned q = (unsigned)(ps + 32 * i);
+        rdst[i] = q * 64u + ((((unsigned)l8 >> 1) ^ ((q >> 2) & 3u)) << 4) + ((unsigned)l8 & 1u) * 8u;
+      }
+    }
+    auto setup_raw = [&](int j) {
+      int tm, tn;
+      tile_of(j, tm, tn);
+      const int pr_lo = row_lo(tm);
+      rok = 0u;
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) {
+        const int q = ps + 32 * i, r = q >> 4, ix = (q & 15) - 1, pr = pr_lo + r;
+        const int b = pr / (H + 1), rr = pr - b * (H + 1);
+        const bool ok = r < RMAX && rr != 0 && b < nimg && (unsigned)ix < (unsigned)W;
+        const int pix = ok ? (b * H + rr - 1) * W + ix : 0;
+        roff[i] = (unsigned)pix * ((unsigned)p.a_ld * 4u) + (unsigned)l8 * 16u;
+        if (ok) rok |= 1u << i;
+      }
+    };
+    auto issue_raw = [&](int n) {                            // n-th chunk of the work list: its loads into `ra`
+      const bool in_piece = n >= ntl * NC;
+      const int cc = in_piece ? pc0 + (n - ntl * NC) : n % NC;
+      if (in_piece ? n == ntl * NC : cc == 0) setup_raw(in_piece ? ntl : n / NC);
+      rcc = (unsigned)cc;
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) {
+        const unsigned vo = roff[i] + (unsigned)cc * 128u;
+        // ("+v": the destination IS the register the value lives in across the tap loop - a fresh output register would have to be
+        //  copied into the loop-carried one right here, before the data has arrived)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(ra[i]) : "v"(vo), "s"(p.a_raw) : "memory");
+      }
+    };
+    const float relu_floor = p.a_relu ? 0.f : -__builtin_inff();
+    auto transform_raw = [&](int n) {                        // registers -> the two plane images of halo buffer n & 1 (after the loads have landed)
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) asm volatile("" : "+v"(ra[i]) :: "memory");
+      u32x4 scq, shq;
+      const unsigned tab = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)halo_bn_tab + (rcc * 32u + (unsigned)l8 * 4u) * 4u;
+      bf3_lds_read(scq, tab); bf3_lds_read(shq, tab + (unsigned)kHaloBnTab * 4u);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(scq), "+v"(shq)::"memory");
+      const float4 s4 = __builtin_bit_cast(float4, scq), t4 = __builtin_bit_cast(float4, shq);
+      const unsigned hbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)(smem + (n & 1) * HBUF);
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < NRAW; ++i) {
+        if (i == NRAW - 1 && ps >= (RMAX * HROW - 32 * (NRAW - 1))) break;      // slot beyond the 208 of the buffer (wave-uniform: ps = 8 * wave + lane / 8)
+        const bool ok = (rok >> i) & 1u;
+        float v[4];
+        v[0] = ok ? fmaxf(fmaf(ra[i].x, s4.x, t4.x), relu_floor) : 0.f;
+        v[1] = ok ? fmaxf(fmaf(ra[i].y, s4.y, t4.y), relu_floor) : 0.f;
+        v[2] = ok ? fmaxf(fmaf(ra[i].z, s4.z, t4.z), relu_floor) : 0.f;
+        v[3] = ok ? fmaxf(fmaf(ra[i].w, s4.w, t4.w), relu_floor) : 0.f;
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+        u32x2_ q1, q2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x2_ xx = f32x2_{v[2 * u], v[2 * u + 1]} * kF16ActScale;
+          const f16x2_ h1 = __builtin_convertvector(xx, f16x2_);
+          const f32x2_ r1 = xx - __builtin_convertvector(h1, f32x2_);
+          q1[u] = __builtin_bit_cast(unsigned, h1); q2[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_));
+        }
+        const unsigned dst = hbase + rdst[i];
+        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(q1) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(q2), "i"(HPLANE * 2) : "memory");
+      }
+      // overflow guard (common.h): a NaN input survives neither fmaxf nor this compare - !(mx <= bound) catches it
+      if (!(mx <= kF16Max / kF16ActScale)) f16x2_raise(p.status, 4u);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     // weight slot s = (tile, chunk, tap) in that order, K offset tap*C + 32*chunk
     typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
     int pj = 0, pcc = ntl > 0 ? 0 : pc0, pend = ntl > 0 ? NC : pc0 + npc, ptap = 0, pst = 0;
@@ -1189,12 +1318,14 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
         }
       }
     };
-    issue_halo(0);
+    constexpr int NHI = BNA ? NRAW : NHALO;        // vector-memory instructions a halo chunk costs this wave
+    if constexpr (BNA) issue_raw(0); else issue_halo(0);
 #pragma unroll
     for (int s0 = 0; s0 < NSTB; ++s0)
       if (s0 < total) issue_b();
     if (total >= NSTB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");     // halo chunk 0 and weight tile 0 (NB each younger tile)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (BNA) transform_raw(0);
     __builtin_amdgcn_s_barrier();
     int g = 0, n = 0;
     bool halo_prev = false;                        // the previous slot issued a halo chunk (10 instructions before its weights)
@@ -1205,12 +1336,17 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
           // weight tile g+1 (and, before tap 0 of a chunk, that chunk's halo - older still) must have landed; younger, in issue
           // order: the previous slot's halo chunk (10, if it issued one) and weight tile g+2 (6)
           if (g + 2 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else if (halo_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NHALO + NB) : "memory");
+          else if (halo_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NHI + NB) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
           __builtin_amdgcn_s_barrier();
           halo_prev = false;
-          if (tap == 0 && n + 1 < nchunks) { if (!(ABL & 2)) issue_halo(n + 1); halo_prev = !(ABL & 2); }
+          if (tap == 0 && n + 1 < nchunks) {
+            if constexpr (BNA) issue_raw(n + 1); else if (!(ABL & 2)) issue_halo(n + 1);
+            halo_prev = BNA || !(ABL & 2);
+          }
           if (!(ABL & 1) && g + NSTB < total) issue_b();
+          // (BNA) the loads issued at tap 0 are older than weight tile g+3 of that tap, which the wait of tap 2 has seen land
+          if constexpr (BNA) if (tap == 2 && n + 1 < nchunks) transform_raw(n + 1);
         }
     return;
   }
@@ -1385,6 +1521,7 @@ static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the 
 static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
+static int g_bf3_few_remap = 1;        // few-tiles launches: slice z on XCD z (codes 92 / 93)
 static int g_bf3_wgrad_persist = 1;    // weight gradients with 32..255 output tiles of 128x128: on the persistent kernel, every tile in K slices (codes 118 / 119)
 static int g_bf3_remainder_grid = 256; // ... and the workgroups such a launch may use
 static int g_bf3_ws256 = 1;            // codes 80 / 81: 256x128 form of the warp-specialised kernel for f16x2 row-major plain-epilogue launches by policy (default) / never
@@ -1433,6 +1570,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
   if (code == 112 || code == 113) { g_bf3_producers = code == 112 ? 4 : 8; return 0; }      // f16x2 on-the-fly-operand kernel: four / eight (default) producer waves
   if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }
+  if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
   if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)          // ... its input slots in flight per producer wave: four (default) / six
 #ifdef DIC_EXPERIMENTS
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
@@ -1576,6 +1714,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (fullr == 0 && few_sp > 0 && !halo && g_bf3_remainder_split && tail_ws) {      // few tiles, long K: every tile in slices
       persist_grid = r * few_sp; rem128 = r;
       p.tail_first_tile = 0; p.tail_split = few_sp; p.tail_ws = tail_ws;
+      p.few_remap = g_bf3_few_remap;
     } else
     if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4) {
       // tail_ws holds tail_ws_slabs slabs of [64][64] floats (kGemmTailWsBytes = 256 for callers of the C ABI, 1024 inside the
@@ -1591,8 +1730,9 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       }
     }
   }
-  if (p.a_raw && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) {      // on-the-fly operand: persistent 1x1 kernel or nothing
-    if (!probe)      // (a caller that gets 1 takes the plane route; one that cannot - dic_debug_conv1x1_bn* - reports this text)
+  const bool halo_bna = halo && p.a_raw && p.fmt == 1 && !p.a_res && !p.a_out && cg.C <= kHaloBnTab && g_bf3_ablate == 0;      // 3x3 halo kernel with the on-the-fly operand
+  if (p.a_raw && !halo_bna && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) {      // on-the-fly operand: persistent 1x1 kernel, the halo kernel, or nothing
+    if (!probe && !im)      // (a caller that gets 1 takes the plane route; one that cannot - dic_debug_conv1x1_bn* - reports this text)
       set_last_error("conv1x1 with on-the-fly BatchNorm operand: shape M=%d C=%d -> CO=%d is not eligible (the launch policy keeps it off "
                      "the persistent 128x128 kernel: needs CO %% 128 == 0, C %% 32 == 0, C > 32 and enough output tiles to fill the CUs); "
                      "nothing was launched", p.M, p.K, p.N);
@@ -1603,7 +1743,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // cost 2 B per plane and element; an im2col A operand is its input image (each pixel read once, not once per tap); the on-the-fly
   // operand reads the raw fp32 tensor (+ the residual) and may write the fp32 copy of its input
   double abytes = (double)p.N * p.K * 2.0 * (p.fmt == 1 ? 2 : 3) + (double)p.M * p.N * 4.0;
-  if (p.a_raw) abytes += (double)p.M * p.K * 4.0 * (1 + (p.a_res ? 1 : 0) + (p.a_out ? 1 : 0));
+  if (p.a_raw && im) abytes += (double)(p.M / std::max(1, cg.OH * cg.OW)) * cg.H * cg.W * cg.C * 4.0;      // (halo kernel: the raw input image once)
+  else if (p.a_raw) abytes += (double)p.M * p.K * 4.0 * (1 + (p.a_res ? 1 : 0) + (p.a_out ? 1 : 0));
   else if (im) abytes += (double)(p.M / std::max(1, cg.OH * cg.OW)) * cg.H * cg.W * cg.C * 2.0 * (p.fmt == 1 ? 2 : 3);
   else abytes += (double)p.M * p.K * 2.0 * (p.fmt == 1 ? 2 : 3);
   gemm_profile_mark_begin(st, 2.0 * p.M * p.N * (double)p.K, (p.fmt == 1 ? 3000 : 2000) + (p.a_raw ? OPK_ROWK_BN : p.A.kind) * 10 + (halo ? 6 : (persist && ws256) ? 7 : (persist && !g_bf3_ws) ? 8 : persist ? 5 : pipe ? 4 : (tmv - 1) * 2 + (tnv - 1)), abytes);
@@ -1616,7 +1757,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (p.a_raw && (g_bf3_bn_ablate & 2)) p.a_out = nullptr;
 #endif
     if (p.fmt == 1) {
-      if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
+      if (halo_bna) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1>), dim3(grid), dim3(512), 0, st, p);
@@ -1793,6 +1935,34 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
   p.ep.stats = bn_partial;
   p.fmt = fmt;
   if (fmt == 1) p.ep.alpha = out_scale;      // 1 / (kF16ActScale * weight scale): the producer waves scale the activations by kF16ActScale
+  if (bn_fused) *bn_fused = 0;
+  const int rc = launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs);
+  if (rc != DIC_OK) return rc;
+  if (mtiles_out) *mtiles_out = g_last_mtiles;
+  return DIC_OK;
+}
+
+// 3x3 / stride 1 / pad 1 convolution of 14x14 maps whose input is formed on the fly (f16x2 format): y_raw = conv(act(raw * scale[c] +
+// shift[c])), the BatchNorm-apply + ReLU + split of the input done by the producer waves of the LDS-halo kernel (BNA form) instead of
+// a bn_apply_planes pass.  Returns DIC_OK, 1 when the launch policy would not run this shape on that kernel (nothing launched: the
+// caller takes the plane route), or a negative error.
+int conv3x3_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, int relu, const ConvDesc& d,
+                       const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, float* tail_ws,
+                       int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused, int fmt, float out_scale, unsigned* status) {
+  if (fmt != 1 || d.in_nchw || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.C % 32 != 0 || d.C > kHaloBnTab ||
+      (long long)d.B * d.H * d.W * d.C * 4 >= (1ll << 32))
+    return 1;
+  DIC_REQUIRE(raw && scale && shift && y, "conv3x3_fwd_bf3_bn: null pointer");
+  Bf3Params p{};
+  p.M = d.M(); p.N = d.CO; p.K = d.K();
+  for (int i = 0; i < 3; ++i) { p.A.p[i] = nullptr; p.B.p[i] = w_planes[i]; }
+  p.A.kind = OPK_IM2COL; p.A.ld = d.C; p.A.g = d.geom(); p.A.paired = 1;
+  p.B.kind = OPK_ROWK; p.B.ld = d.K(); p.B.paired = 1;
+  p.a_raw = raw; p.a_scale = scale; p.a_shift = shift; p.a_ld = d.C; p.a_relu = relu;
+  p.status = status;
+  p.ep = ep_store(y, d.CO, nullptr, ACT_NONE);
+  p.ep.stats = bn_partial;
+  p.fmt = 1; p.ep.alpha = out_scale;
   if (bn_fused) *bn_fused = 0;
   const int rc = launch_bf3(p, st, tail_ws, 1, nullptr, bn_fuse, bn_fused, tail_ws_slabs);
   if (rc != DIC_OK) return rc;

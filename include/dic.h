@@ -425,6 +425,9 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   100..104     ResNet forward, BatchNorm-apply passes folded into the consuming 1x1 convolution's operand path: none (every
  *                convolution input is written as planes first) / block outputs only / conv2 outputs only / both / by operand
  *                format (default: both in mode 1, block outputs only in mode 2)
+ *   108 109      mode 2: conv1's BatchNorm-apply + ReLU + split formed inside the LDS-halo 3x3 kernel's producer waves (no planes pass): never /
+ *                wherever that kernel takes the shape (default)
+ *   92 93        few-tiles launches (every output tile cut into K slices): plain workgroup order / K slice z on XCD z (default)
  *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
  *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
  *   116 117      depth encoder conv2 / conv3 (forward and both gradients): exact bf16x3 split / f16x2 with device-resident scales (default)

@@ -10,6 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt-mode --no-overlap > $OUT/bench_n1_no_overlap.json 2>> $OUT/bench_n1.err
 python3 $R/bench.py --steps 5 --warmup 2 --batch 256 --no-cpu-baseline > $OUT/bench_n1_batch256.json 2>> $OUT/bench_n1.err
+python3 $R/bench.py --steps 20 --warmup 5 --batch 32 --no-cpu-baseline --no-decoder-batch256 > $OUT/bench_n1_batch32.json 2>> $OUT/bench_n1.err      # config 3's per-rank shape
+python3 $R/bench.py --steps 10 --warmup 3 --hard --no-decoder-batch256 > $OUT/bench_hard_n1.json 2>> $OUT/bench_n1.err
+echo "bench lines done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-alt-mode > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_no_overlap -o run -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-alt-mode --no-overlap > /dev/null 2>> $OUT/rocprof.err
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do

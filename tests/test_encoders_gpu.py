@@ -265,6 +265,32 @@ def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(
             assert torch.equal(y, y0) and torch.equal(st, s0), (code, dy, ds)
 
 
+def test_resnet_forward_with_bn_apply_inside_the_halo_kernel_matches_plane_route(lib):
+    """Round 4: in the f16x2 format the 3x3 convolutions of 14x14 maps (35 of the 50 blocks) read the RAW output of conv1 and form
+    relu(bn1(.)) in the LDS-halo kernel's producer waves (switch 109, default) instead of reading planes written by a bn_apply_planes
+    pass (108).  Same element-wise arithmetic (one fused multiply-add, max, scale by 4, the two fp16 roundings), same LDS image, same
+    products in the same order: features and every running statistic agree bit for bit, the guard word stays clear, and the
+    default reproduces itself."""
+    w = syn.resnet152_weights(seed=125)
+    imgs = syn.rgb_images(64, seed=123).to(DEV)
+    results = {}
+    try:
+        for code in (108, 109, 109):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            wd = _dev(w)
+            runner = native.ResNetRunner(wd, conv_mode="f16x2")
+            y = runner.forward(imgs, train_bn=True, compact=True)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and int(runner.status_word().item()) == 0
+            stats = torch.cat([wd[k].flatten() for k in sorted(wd) if "running" in k])
+            if code in results:
+                assert torch.equal(results[code][0], y) and torch.equal(results[code][1], stats), "switch 109 does not reproduce itself"
+            results[code] = (y.clone(), stats.clone())
+    finally:
+        lib.dic_debug_force_staged_gemm(109)
+    assert torch.equal(results[108][0], results[109][0]) and torch.equal(results[108][1], results[109][1])
+
+
 def test_layer1_kernels_reproducible_next_to_lds_heavy_kernels(lib):
     """The packed-FMA layer-1 kernels of the depth encoder (csrc/conv1_depth.hip), called alone through the library, repeated
     on identical inputs while a bf16x3 ResNet forward on its round-1 gather kernels (debug codes 70 75: three LDS-heavy

@@ -561,6 +561,82 @@ def test_conv1x1_on_the_fly_operand_f16x2(lib, M, Cin, CO, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,CO", [(64, 256, 256), (40, 96, 128), (3, 64, 128), (67, 512, 128)])
+def test_conv3x3_halo_kernel_with_on_the_fly_operand(lib, B, Cin, CO):
+    """Round 4: the LDS-halo 3x3 kernel reading the RAW fp32 output of the convolution before it, its producer waves forming
+    relu(raw * scale + shift), scaling by 4 and writing the two fp16 plane images (conv3x3_fwd_bf3_bn) - against the same kernel fed
+    with planes of the same activation evaluated in torch (same LDS image, same products in the same order: bit-identical outputs -
+    tests/test_encoders_gpu.py asserts exactly that against the bn_apply_planes route on the whole network), against fp64,
+    BatchNorm partial sums, a ragged last tile / tiles spanning images / 2..16 channel chunks, repeated launches, and the overflow
+    guard: one raw value whose activation leaves the fp16 range raises the status word (bit 4: producer waves)."""
+    import torch.nn.functional as F
+    H = 14
+    M = B * H * H
+    g = torch.Generator().manual_seed(B + Cin + CO)
+    raw = torch.randn(B, H, H, Cin, generator=g).to(DEV)
+    scale = (torch.rand(Cin, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cin, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(CO, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(DEV)
+    # the kernel's raw * scale + shift is ONE fused multiply-add; in fp64 the product of two floats is exact and the sum rounds at 53
+    # bits, so rounding that to fp32 is the fused result (up to a double rounding in about one element in 2^29)
+    act = torch.relu((raw.double() * scale.double() + shift.double()).float())
+    w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
+    out_scale = C.c_float(1.0 / (4.0 * w_scale))
+
+    def split(x2d, s):
+        R, K = x2d.shape
+        out = [torch.zeros((R + 1) // 2 * 2 * K, dtype=torch.int16, device=DEV) for _ in range(2)]
+        check(lib.dic_split_f16x2_paired(ptr(x2d), C.c_longlong(R), K, C.c_float(s), ptr(out[0]), ptr(out[1]), stream_ptr()), "split")
+        return out
+
+    pl = lambda ps: (C.c_void_p * 3)(ps[0].data_ptr(), ps[1].data_ptr(), None)            # noqa: E731
+    xp, wp = split(act.reshape(M, Cin).contiguous(), 4.0), split(w.view(CO, -1), w_scale)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    try:
+        assert lib.dic_debug_force_staged_gemm(74) == 0            # the halo kernel whatever the tile count
+        y_pl = torch.full((M, CO), float("nan"), device=DEV)
+        check(lib.dic_debug_conv_fmt(pl(xp), B, H, H, Cin, pl(wp), CO, 3, 1, 1, ptr(y_pl), None, None, ptr(tail), 1, out_scale, stream_ptr()), "planes")
+        ys = []
+        for rep in range(3):
+            y = torch.full((M, CO), float("nan"), device=DEV)
+            part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+            mt = C.c_int(0)
+            rc = lib.dic_debug_conv3x3_bn(ptr(raw), ptr(scale), ptr(shift), 1, B, H, H, Cin, pl(wp), CO, ptr(y), ptr(part), C.byref(mt), ptr(tail), 1024,
+                                          out_scale, ptr(status), stream_ptr())
+            assert rc == 0, (rc, lib.dic_last_error())
+            torch.cuda.synchronize()
+            ys.append(y)
+        assert torch.isfinite(ys[0]).all() and int(status.item()) == 0
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), "repeated launches differ"
+        ndiff = int((ys[0] != y_pl).sum())          # (a double-rounded activation element would show in its 9 * CO outputs, at rounding level)
+        assert ndiff <= 3 * 9 * CO and float((ys[0] - y_pl).abs().max()) <= 2e-6 * float(y_pl.abs().max()), (ndiff, float((ys[0] - y_pl).abs().max()))
+        print(f"\noutputs that differ from the plane route: {ndiff} of {M * CO}")
+        ref = F.conv2d(act.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, CO)
+        sc = float(ref.abs().max())
+        err = float((ys[0].double().cpu() - ref).abs().max()) / sc
+        print(f"\n3x3 halo, on-the-fly operand, {B}x14x14x{Cin} -> {CO}: max err / scale vs fp64 {err:.2e}")
+        assert err < 4e-6
+        stats = part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu()
+        assert torch.allclose(stats[0], ref.sum(0), rtol=1e-4, atol=1e-3 * sc) and torch.allclose(stats[1], (ref * ref).sum(0), rtol=1e-4, atol=1e-3 * sc)
+        # the guard: relu(2e4 * scale + shift) * 4 is beyond fp16
+        raw2 = raw.clone()
+        raw2[B // 2, 5, 7, 3] = 4.0e4
+        rc = lib.dic_debug_conv3x3_bn(ptr(raw2), ptr(scale), ptr(shift), 1, B, H, H, Cin, pl(wp), CO, ptr(y), ptr(part), C.byref(mt), ptr(tail), 1024,
+                                      out_scale, ptr(status), stream_ptr())
+        torch.cuda.synchronize()
+        assert rc == 0 and int(status.item()) & 4, int(status.item())
+    finally:
+        lib.dic_debug_force_staged_gemm(78)
+    # a shape the halo kernel does not take: nothing launched, the caller's cue to take the plane route
+    y2 = torch.zeros(28 * 28, CO, device=DEV)
+    assert lib.dic_debug_conv3x3_bn(ptr(raw), ptr(scale), ptr(shift), 1, 1, 28, 28, Cin, pl(wp), CO, ptr(y2), None, None, ptr(tail), 1024, out_scale,
+                                    ptr(status), stream_ptr()) == 1
+    torch.cuda.synchronize()
+    assert not bool(y2.any())
+
+
+@pytest.mark.gpu
 def test_f16x2_activation_beyond_fp16_range_fails_loudly(lib):
     """The f16x2 format stores 4 * x in fp16: an activation beyond +-16376 cannot be represented.  The documented behaviour is a loud
     one - the plane holds inf, every output that touches it is inf / NaN - never a silently clamped value; bf16x3 on the same input
