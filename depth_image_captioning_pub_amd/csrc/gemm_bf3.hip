@@ -1130,11 +1130,15 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
 //     for the weight tiles issued after them cover them), transforms and writes the two plane images at tap 2, six K tiles before
 //     the computing waves first read them.  Padding pixels are written as zeros (the padding applies to the activation).
 constexpr int kHaloBnTab = 512;       // channels of the on-the-fly operand of the halo kernel (scale | shift table in LDS)
-template <int ABL, int FMT = 0, bool BNA = false>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
+//   * HROW / RMAX: padded pixels per halo row and halo rows of a tile - 16 / 13 for 14x14 maps; 32 / 9 for 28x28 maps (ResNet layer 2;
+//     BNA form only: its halo buffers hold the two f16x2 planes, 2 x 36 KB, where three planes of that size would not fit).  RMAX is the
+//     largest number of padded rows any 128-pixel tile touches (brute force over every tile start: 13 | 9).
+template <int ABL, int FMT = 0, bool BNA = false, int HROW = 16, int RMAX = 13>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
 __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p) {
   static_assert(!BNA || FMT == 1, "on-the-fly halo operand: f16x2 only");
-  constexpr int BM = 128, BN = 128, NSTB = 3, HROW = 16, RMAX = 13;
-  constexpr int HPLANE = RMAX * HROW * BK3, HBUF = 3 * HPLANE;        // elements: 13 KB per plane, 39 KB per buffer
+  static_assert((HROW == 16 && RMAX == 13) || (BNA && HROW == 32 && RMAX == 9), "halo geometry: 14x14 maps, or 28x28 with the on-the-fly operand");
+  constexpr int BM = 128, BN = 128, NSTB = 3;
+  constexpr int HPLANE = RMAX * HROW * BK3, HBUF = (BNA ? Bf3Fmt<FMT>::NPL : 3) * HPLANE;        // elements: 13 KB per plane, 39 KB per buffer (14x14)
   constexpr int BPLANE = BN * BK3, BSTAGE = 3 * BPLANE;               // 24 KB per weight tile
   constexpr int NPL = Bf3Fmt<FMT>::NPL;                               // planes in use (buffers keep three plane slots)
   constexpr int NHALO = (RMAX * NPL + 3) / 4;                          // halo DMA instructions per producer wave and chunk (10 | 7)
@@ -1216,10 +1220,10 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       }
     };
     // ---- on-the-fly operand (BNA): thread (ps, l8) of the 256 producer threads owns channels 4*l8 .. 4*l8+3 of the pixel slots
-    // q = ps + 32*i, i < 7 (13 rows x 16 padded pixels = 208 slots; i = 6 exists for ps < 16 only).  Every thread ALWAYS issues its
-    // seven loads (slots that are padding, beyond the batch or beyond the buffer read element 0 and are replaced by zeros): the
-    // counted waits rely on the instruction count.
-    constexpr int NRAW = 7;
+    // q = ps + 32*i, i < NRAW (14x14: 13 rows x 16 padded pixels = 208 slots, NRAW = 7, i = 6 exists for ps < 16 only; 28x28: 9 x 32 =
+    // 288 slots, NRAW = 9).  Every thread ALWAYS issues its NRAW loads (slots that are padding, beyond the batch or beyond the buffer
+    // read element 0 and are replaced by zeros): the counted waits rely on the instruction count.
+    constexpr int NRAW = (RMAX * HROW + 31) / 32;
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
     f32x4_ ra[BNA ? NRAW : 1];
 #pragma unroll
@@ -1241,7 +1245,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       rok = 0u;
 #pragma unroll
       for (int i = 0; i < NRAW; ++i) {
-        const int q = ps + 32 * i, r = q >> 4, ix = (q & 15) - 1, pr = pr_lo + r;
+        const int q = ps + 32 * i, r = q / HROW, ix = (q % HROW) - 1, pr = pr_lo + r;
         const int b = pr / (H + 1), rr = pr - b * (H + 1);
         const bool ok = r < RMAX && rr != 0 && b < nimg && (unsigned)ix < (unsigned)W;
         const int pix = ok ? (b * H + rr - 1) * W + ix : 0;
@@ -1278,7 +1282,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       float mx = 0.f;
 #pragma unroll
       for (int i = 0; i < NRAW; ++i) {
-        if (i == NRAW - 1 && ps >= (RMAX * HROW - 32 * (NRAW - 1))) break;      // slot beyond the 208 of the buffer (wave-uniform: ps = 8 * wave + lane / 8)
+        if (i == NRAW - 1 && ps >= (RMAX * HROW - 32 * (NRAW - 1))) break;      // slot beyond the buffer (14x14: 208 slots; wave-uniform: ps = 8 * wave + lane / 8)
         const bool ok = (rok >> i) & 1u;
         float v[4];
         v[0] = ok ? fmaxf(fmaf(ra[i].x, s4.x, t4.x), relu_floor) : 0.f;
@@ -1521,6 +1525,7 @@ static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the 
 static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
+static int g_bf3_halo28 = 1;           // 3x3 convolutions of 28x28 maps with the on-the-fly operand on the LDS-halo kernel (codes 94 / 95)
 static int g_bf3_few_remap = 1;        // few-tiles launches: slice z on XCD z (codes 92 / 93)
 static int g_bf3_wgrad_persist = 1;    // weight gradients with 32..255 output tiles of 128x128: on the persistent kernel, every tile in K slices (codes 118 / 119)
 static int g_bf3_remainder_grid = 256; // ... and the workgroups such a launch may use
@@ -1570,7 +1575,8 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
   if (code == 112 || code == 113) { g_bf3_producers = code == 112 ? 4 : 8; return 0; }      // f16x2 on-the-fly-operand kernel: four / eight (default) producer waves
   if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }
-  if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
+  if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }
+  if (code == 94 || code == 95) { g_bf3_halo28 = code - 94; return 0; }                      // LDS-halo kernel for 28x28 maps (on-the-fly operand form): never / by policy (default)                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
   if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)          // ... its input slots in flight per producer wave: four (default) / six
 #ifdef DIC_EXPERIMENTS
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
@@ -1665,8 +1671,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   }
   // 3x3 convolutions of 14x14 maps: the LDS-halo kernel
   const ConvGeom& cg = p.A.g;
+  // (28x28 maps - ResNet layer 2 - only in the form that takes the raw input and forms the activation in the producer waves, f16x2)
+  const bool halo28 = g_bf3_halo28 != 0 && cg.H == 28 && cg.W == 28 && p.a_raw && p.fmt == 1 && !p.a_res && !p.a_out && cg.C <= kHaloBnTab;
   const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && plain_ep && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
-                    cg.stride == 1 && cg.pad == 1 && cg.H == 14 && cg.W == 14 && cg.nchw == 0 && cg.C % BK3 == 0 &&
+                    cg.stride == 1 && cg.pad == 1 && ((cg.H == 14 && cg.W == 14) || halo28) && cg.nchw == 0 && cg.C % BK3 == 0 &&
                     p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
   if (halo) persist = true;
   if (persist) { tmv = 2; tnv = 2; }
@@ -1757,7 +1765,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (p.a_raw && (g_bf3_bn_ablate & 2)) p.a_out = nullptr;
 #endif
     if (p.fmt == 1) {
-      if (halo_bna) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      if (halo_bna && cg.W == 28) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true>), dim3(grid), dim3(512), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);

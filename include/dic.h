@@ -427,6 +427,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *                format (default: both in mode 1, block outputs only in mode 2)
  *   108 109      mode 2: conv1's BatchNorm-apply + ReLU + split formed inside the LDS-halo 3x3 kernel's producer waves (no planes pass): never /
  *                wherever that kernel takes the shape (default)
+ *   94 95        3x3 convolutions of 28x28 maps (layer 2) with that on-the-fly operand on the LDS-halo kernel: never (gathered kernel + planes
+ *                pass) / by policy (default)
  *   92 93        few-tiles launches (every output tile cut into K slices): plain workgroup order / K slice z on XCD z (default)
  *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
  *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
