@@ -64,9 +64,11 @@ int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw
                    int fmt = 0, const float* dy_slot = nullptr /* f16x2: the gradient's device-resident {scale, 1 / scale} (F16Scale::slot) */);
 // 7x7 stride-2 pad-3 stem with C_in = 3 on the bf16x3 kernel (strip formulation, see gemm_bf3.hip)
 size_t conv_stem_bf3_plane_elems(int B, int H, int W);
-int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st);
+int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st,
+                           float f16_scale = 0.f /* > 0: two f16x2 planes of f16_scale * w instead of three bf16 planes */);
 int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned short* const x_planes[3],
-                  const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st);
+                  const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st,
+                  int fmt = 0, float out_scale = 1.0f, unsigned* status = nullptr /* f16x2: image planes of 4 * x, guarded */);
 int conv_dgrad_s1_bf3(const unsigned short* const dy_planes[3], const ConvDesc& d,
                       const unsigned short* const wflip_planes[3], float* dx, hipStream_t st, float* tail_ws = nullptr,
                       int tail_ws_slabs = 256, int fmt = 0, const float* alpha_dev0 = nullptr, const float* alpha_dev1 = nullptr);

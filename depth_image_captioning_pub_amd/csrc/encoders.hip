@@ -346,11 +346,13 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
   {   // stem (C_in = 3, 1 % of the FLOPs): exact-fp32 gather kernel, then BN + ReLU + maxpool, then split into planes
     const RnConv& c = pl.convs[ci++];
     const dic_conv_bn_layer& L0 = layers[c.layer];
-    if (g_strip_stem && L0.w_hi && L0.w_mid && L0.w_lo && c.d.H % 2 == 0 && c.d.W % 2 == 0) {
+    const bool stem_f16 = fmt && L0.w_hi && L0.w_mid && !L0.w_lo && L0.w_scale > 0.f;      // layer 0 carries f16x2 strip planes (dic_resnet_pack_stem_weights_f16x2)
+    if (g_strip_stem && L0.w_hi && L0.w_mid && (L0.w_lo || stem_f16) && c.d.H % 2 == 0 && c.d.W % 2 == 0) {
       // strip formulation on the bf16x3 kernel (w_hi/mid/lo of layer 0 = dic_resnet_pack_stem_weights)
       int mtiles = 0;
       const unsigned short* wp[3] = {L0.w_hi, L0.w_mid, L0.w_lo};
-      DIC_TRY(conv_stem_bf3(imgs_nchw, B, c.d.H, c.d.W, 64, ws.stem_planes, wp, R3, train_bn ? ws.partial : nullptr, &mtiles, st));
+      DIC_TRY(conv_stem_bf3(imgs_nchw, B, c.d.H, c.d.W, 64, ws.stem_planes, wp, R3, train_bn ? ws.partial : nullptr, &mtiles, st,
+                            stem_f16 ? 1 : 0, stem_f16 ? 1.0f / (kF16ActScale * L0.w_scale) : 1.0f, guard));
       if (train_bn)
         DIC_TRY(bn_finalize_train(ws.partial, mtiles, c.d.M(), 64, L0.gamma, L0.beta, L0.running_mean, L0.running_var, ws.bn,
                                   ws.red, st, guard));
@@ -686,6 +688,12 @@ int dic_resnet_pack_stem_weights(const float* w_oihw, float* scratch_f32, uint16
   DIC_REQUIRE(w_oihw && scratch_f32 && w_hi && w_mid && w_lo, "resnet_pack_stem_weights: null pointer");
   unsigned short* wp[3] = {w_hi, w_mid, w_lo};
   return conv_stem_pack_weights(w_oihw, 64, scratch_f32, wp, (hipStream_t)stream);
+}
+
+int dic_resnet_pack_stem_weights_f16x2(const float* w_oihw, float* scratch_f32, uint16_t* w_h1, uint16_t* w_h2, float w_scale, void* stream) {
+  DIC_REQUIRE(w_oihw && scratch_f32 && w_h1 && w_h2 && w_scale > 0.f, "resnet_pack_stem_weights_f16x2: null pointer / scale");
+  unsigned short* wp[3] = {w_h1, w_h2, nullptr};
+  return conv_stem_pack_weights(w_oihw, 64, scratch_f32, wp, (hipStream_t)stream, w_scale);
 }
 
 int dic_resnet_num_layers(const int* blocks) {

@@ -2097,7 +2097,7 @@ int conv_wgrad_bf3(const float* x, const ConvDesc& d, const float* dy, float* dw
 __global__ void __launch_bounds__(256) stem_pack_image_kernel(const float* __restrict__ img, int B, int H, int W, int Hp,
                                                                int Wp, unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
-                                                               unsigned short* __restrict__ lo) {
+                                                               unsigned short* __restrict__ lo, unsigned* __restrict__ status) {      // lo == NULL: f16x2 planes of kF16ActScale * image (guarded)
   const long long total = (long long)B * Hp * Wp;         // one thread per padded pixel (4 channels = 8 B per plane)
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
@@ -2109,11 +2109,18 @@ __global__ void __launch_bounds__(256) stem_pack_image_kernel(const float* __res
     unsigned short a[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
     if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) split3_bf16(img[((b * 3 + c) * H + h) * W + w], a[c], m[c], l[c]);
+      for (int c = 0; c < 3; ++c) {
+        const float v = img[((b * 3 + c) * H + h) * W + w];
+        if (lo) split3_bf16(v, a[c], m[c], l[c]);
+        else {
+          if (f16x2_out_of_range(v, kF16ActScale)) f16x2_raise(status, 16u);
+          split2_f16(v, kF16ActScale, a[c], m[c]);
+        }
+      }
     }
     reinterpret_cast<uint2*>(hi)[i] = make_uint2((unsigned)a[0] | ((unsigned)a[1] << 16), (unsigned)a[2] | ((unsigned)a[3] << 16));
     reinterpret_cast<uint2*>(mid)[i] = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-    reinterpret_cast<uint2*>(lo)[i] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    if (lo) reinterpret_cast<uint2*>(lo)[i] = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
   }
 }
 
@@ -2127,29 +2134,33 @@ __global__ void __launch_bounds__(256) stem_pack_weights_kernel(const float* __r
 
 size_t conv_stem_bf3_plane_elems(int B, int H, int W) { return (size_t)B * (H + 6) * (W + 8) * 4 + 64; }
 
-int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st) {
+int conv_stem_pack_weights(const float* w_oihw, int CO, float* scratch_f32, unsigned short* const w_planes[3], hipStream_t st, float f16_scale) {
   hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(CO * 224, 256)), dim3(256), 0, st, w_oihw, CO, scratch_f32);
   DIC_LAUNCH_CHECK();
+  if (f16_scale > 0.f) return split_f16x2_paired(scratch_f32, CO, 224, f16_scale, w_planes[0], w_planes[1], st, nullptr);      // (two planes of f16_scale * w)
   return split_bf16x3_paired(scratch_f32, CO, 224, w_planes[0], w_planes[1], w_planes[2], st);
 }
 
 // y_raw[B,OH,OW,CO] = conv7x7s2p3(imgs NCHW) with BN partial sums; x_planes: conv_stem_bf3_plane_elems(B,H,W) each
 int conv_stem_bf3(const float* imgs_nchw, int B, int H, int W, int CO, unsigned short* const x_planes[3],
-                  const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st) {
+                  const unsigned short* const w_planes[3], float* y, float* bn_partial, int* mtiles_out, hipStream_t st, int fmt,
+                  float out_scale, unsigned* status) {
   DIC_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_stem_bf3: even image sizes");
   const int Hp = H + 6, Wp = W + 8, OH = H / 2, OW = W / 2;
   const long long px = (long long)B * Hp * Wp;
   hipLaunchKernelGGL(stem_pack_image_kernel, dim3((unsigned)std::min<long long>((px + 255) / 256, 16384)), dim3(256), 0, st,
-                     imgs_nchw, B, H, W, Hp, Wp, x_planes[0], x_planes[1], x_planes[2]);
+                     imgs_nchw, B, H, W, Hp, Wp, x_planes[0], x_planes[1], fmt ? nullptr : x_planes[2], status);
   DIC_LAUNCH_CHECK();
   Bf3Params p{};
   p.M = B * OH * OW; p.N = CO; p.K = 224;
   for (int i = 0; i < 3; ++i) { p.A.p[i] = x_planes[i]; p.B.p[i] = w_planes[i]; }
+  if (fmt) { p.A.p[2] = p.B.p[2] = nullptr; p.fmt = 1; }
   p.A.kind = OPK_IM2COL; p.A.ld = 4; p.A.paired = 0;
   p.A.g = ConvGeom{Hp, Wp, 4, OH, OW, 7, 1, 2, 0, 2};        // nchw = 2: strip mode of the loader
   p.B.kind = OPK_ROWK; p.B.ld = 224; p.B.paired = 1;
   p.ep = ep_store(y, CO, nullptr, ACT_NONE);
   p.ep.stats = bn_partial;
+  if (fmt) p.ep.alpha = out_scale;      // 1 / (kF16ActScale * weight scale)
   DIC_TRY(launch_bf3(p, st, nullptr));
   if (mtiles_out) *mtiles_out = g_last_mtiles;
   return DIC_OK;

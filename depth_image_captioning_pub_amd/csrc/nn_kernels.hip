@@ -8,6 +8,17 @@ namespace dic {
 
 static inline int ew_blocks(long long n_items) { return (int)std::min<long long>((n_items + 255) / 256, 8192); }
 
+// Division of indices below 2^31 by a runtime constant as one multiply-high: q = (umulhi(x, m) + x) >> s (round-up method; m, s from
+// the host).  Until round 4 the pooling kernels spent most of their time in 64-bit divisions (element -> row, channel; row -> image,
+// y, x): the 175-MB layer-1 map of the depth encoder moved at 2.5-3.5 TB/s through the BatchNorm-pool backward.
+struct FastDiv { unsigned m, s; };
+static inline FastDiv make_fastdiv(unsigned d) {
+  unsigned s = 0;
+  while ((1u << s) < d) ++s;
+  return FastDiv{(unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << s) - d)) / d + 1), s};
+}
+__device__ __forceinline__ unsigned fast_div(unsigned x, FastDiv f) { return (__umulhi(x, f.m) + x) >> f.s; }
+
 // ------------------------------------------------------------------------------------------
 // BatchNorm statistics -> scale/shift
 // ------------------------------------------------------------------------------------------
@@ -321,15 +332,17 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
                                                                unsigned char* __restrict__ idx,
                                                                unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
-                                                               unsigned short* __restrict__ lo, unsigned* __restrict__ status) {
-  const long long total = (long long)B * PH * PW * C4;
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-    const int c4 = (int)(i % C4);
-    long long r = i / C4;
-    const int pw = (int)(r % PW); r /= PW;
-    const int ph = (int)(r % PH);
-    const int b = (int)(r / PH);
+                                                               unsigned short* __restrict__ lo, unsigned* __restrict__ status,
+                                                               FastDiv dC4, FastDiv dPW, FastDiv dPH) {
+  const unsigned total = (unsigned)B * PH * PW * C4;       // < 2^31 (checked by the host)
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += stride) {
+    const unsigned row = fast_div(i, dC4);
+    const int c4 = (int)(i - row * (unsigned)C4);
+    const unsigned r1 = fast_div(row, dPW);
+    const int pw = (int)(row - r1 * (unsigned)PW);
+    const int b = (int)fast_div(r1, dPH);
+    const int ph = (int)(r1 - (unsigned)b * (unsigned)PH);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (has_bn) {
       sc = *reinterpret_cast<const float4*>(bn.scale + c4 * 4);
@@ -356,8 +369,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
     if (y) reinterpret_cast<float4*>(y)[i] = best;
     if (idx) reinterpret_cast<uchar4*>(idx)[i] = bi;
     if (hi) {     // also (or only) as paired bf16x3 planes: the pooled map feeds a bf16x3 convolution (saves the split pass)
-      const long long row = i / C4;
-      const long long off = plane_offset(row, c4 * 4, C4 / 8, 1);
+      const long long off = plane_offset((long long)row, c4 * 4, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
       if (!lo) {    // f16x2 format: two fp16 planes of kF16ActScale * v
         if (f16x2_out_of_range(best.x, kF16ActScale) | f16x2_out_of_range(best.y, kF16ActScale) | f16x2_out_of_range(best.z, kF16ActScale) |
@@ -382,10 +394,11 @@ int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn,
   DIC_REQUIRE(!planes || C % 32 == 0, "maxpool: plane output needs C %% 32");
   const int PH = (H + 2 * p - k) / s + 1, PW = (W + 2 * p - k) / s + 1;
   const long long total = (long long)B * PH * PW * (C / 4);
+  DIC_REQUIRE(total < (1ll << 31) - (1ll << 22), "maxpool: more than 2^31 output elements");      // (32-bit indices: i + grid stride must not wrap)
   BnBuf z{};
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, B, H, W, C / 4, bn ? *bn : z,
                      bn ? 1 : 0, relu, k, s, p, PH, PW, y, idx, planes ? planes[0] : nullptr, planes ? planes[1] : nullptr,
-                     planes ? planes[2] : nullptr, status);
+                     planes ? planes[2] : nullptr, status, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)PW), make_fastdiv((unsigned)PH));
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -625,7 +638,7 @@ int f16_scale_from_absmax(const float* x, long long n, F16Scale sl, hipStream_t 
 
 // BatchNorm backward, stage 1: per (row-chunk, channel) sums of dy and dy*xhat.
 // block = 64 channels (16 float4 lanes) x 16 row lanes; grid (C/64, chunks) with enough row chunks for >= 512 blocks
-constexpr int kBnChunksMax = 256;
+constexpr int kBnChunksMax = 512;      // (256 until round 4: 512 workgroups of 4 rows in flight moved the depth encoder's 175-MB layer-1 map at 2.5 TB/s)
 static inline int reduce_chunks(int C) { return std::min(kBnChunksMax, std::max(64, 1024 / std::max(1, C / 64))); }
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              long long rows, int C, BnBuf bn, float* __restrict__ part,
@@ -802,19 +815,19 @@ int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float
 // passes.  Versus maxpool_relu_bwd + bn_backward this drops one write and two reads of the full-size tensor
 // (layer 1: 175 MB each).
 // ------------------------------------------------------------------------------------------
-struct PoolGeom { int H, W, k, PH, PW; };
+struct PoolGeom { int H, W, k, PH, PW; FastDiv dH, dW, dk; };
 
 __device__ __forceinline__ float4 pool_relu_grad4(const float* __restrict__ dpool, const unsigned char* __restrict__ idx,
-                                                  const float4 v, const float4 sc, const float4 sh, long long row,
-                                                  int c4, int C4, PoolGeom pg) {
-  const int w = (int)(row % pg.W);
-  const long long r2 = row / pg.W;
-  const int h = (int)(r2 % pg.H);
-  const long long b = r2 / pg.H;
-  const int ph = h / pg.k, pw = w / pg.k;
+                                                  const float4 v, const float4 sc, const float4 sh, unsigned row,
+                                                  int c4, int C4, PoolGeom pg) {      // row < 2^31 (checked by the host)
+  const unsigned r2 = fast_div(row, pg.dW);
+  const int w = (int)(row - r2 * (unsigned)pg.W);
+  const unsigned b = fast_div(r2, pg.dH);
+  const int h = (int)(r2 - b * (unsigned)pg.H);
+  const int ph = (int)fast_div((unsigned)h, pg.dk), pw = (int)fast_div((unsigned)w, pg.dk);
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ph < pg.PH && pw < pg.PW) {
-    const long long po = ((b * pg.PH + ph) * pg.PW + pw) * C4 + c4;
+    const long long po = (((long long)b * pg.PH + ph) * pg.PW + pw) * C4 + c4;
     const float4 d = reinterpret_cast<const float4*>(dpool)[po];
     const uchar4 id = reinterpret_cast<const uchar4*>(idx)[po];
     const unsigned char me = (unsigned char)((h - ph * pg.k) * pg.k + (w - pw * pg.k));
@@ -844,15 +857,15 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_reduce_kernel(const float* __
     const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
     const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
     const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
-    for (long long r = r0 + rl; r < r1; r += 64) {        // 4 rows in flight per thread
-      float4 v[4];
+    for (long long r = r0 + rl; r < r1; r += 128) {       // 8 rows in flight per thread
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + min(r + 16 * u, r1 - 1) * C + c);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(x + min(r + 16 * u, r1 - 1) * C + c);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const long long rr = r + 16 * u;
         if (rr < r1) {
-          const float4 g = pool_relu_grad4(dpool, idx, v[u], sc, sh, rr, c >> 2, C >> 2, pg);
+          const float4 g = pool_relu_grad4(dpool, idx, v[u], sc, sh, (unsigned)rr, c >> 2, C >> 2, pg);
           a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
           b.x += g.x * (v[u].x - mu.x) * is.x; b.y += g.y * (v[u].y - mu.y) * is.y;
           b.z += g.z * (v[u].z - mu.z) * is.z; b.w += g.w * (v[u].w - mu.w) * is.w;
@@ -885,20 +898,23 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
                                                                  const float* __restrict__ k3,
                                                                  unsigned short* __restrict__ hi,
                                                                  unsigned short* __restrict__ mid,
-                                                                 unsigned short* __restrict__ lo, const float* __restrict__ f16_slot) {
+                                                                 unsigned short* __restrict__ lo, const float* __restrict__ f16_slot,
+                                                                 FastDiv dC4) {
   const long long stride = (long long)gridDim.x * 256;
   const float fs = f16_slot ? f16_slot[0] : 1.f;      // f16x2 planes (lo == NULL): the device-resident scale of this gradient
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const int c4 = (int)(i % C4), c = c4 * 4;
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
-    const float4 g = pool_relu_grad4(dpool, idx, v, sc, sh, i / C4, c4, C4, pg);
-    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
-    const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 a2 = *reinterpret_cast<const float4*>(k2 + c);
-    const float4 a3 = *reinterpret_cast<const float4*>(k3 + c);
+  // C4 divides 256 (checked by the host) and the grid stride is a multiple of 256: a thread stays on one channel quad, whose nine
+  // per-channel constants are read once; the element's row is a 32-bit quotient
+  const int c4 = (int)(threadIdx.x % (unsigned)C4), c = c4 * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(bn.shift + c);
+  const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c);
+  const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 a2 = *reinterpret_cast<const float4*>(k2 + c);
+  const float4 a3 = *reinterpret_cast<const float4*>(k3 + c);
+  auto finish = [&](long long i, const float4 v) {
+    const unsigned row = fast_div((unsigned)i, dC4);
+    const float4 g = pool_relu_grad4(dpool, idx, v, sc, sh, row, c4, C4, pg);
     float4 o;
     o.x = ga.x * is.x * (g.x - a2.x - (v.x - mu.x) * is.x * a3.x);
     o.y = ga.y * is.y * (g.y - a2.y - (v.y - mu.y) * is.y * a3.y);
@@ -906,7 +922,7 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
     o.w = ga.w * is.w * (g.w - a2.w - (v.w - mu.w) * is.w * a3.w);
     reinterpret_cast<float4*>(dy)[i] = o;
     if (hi) {     // the same gradient as paired bf16x3 planes (operand of the data-gradient convolution)
-      const long long off = plane_offset(i / C4, c, C4 / 8, 1);
+      const long long off = plane_offset((long long)row, c, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
       if (!lo) {      // f16x2 format: two fp16 planes of fs * o
         split2_f16(o.x, fs, h[0], m[0]); split2_f16(o.y, fs, h[1], m[1]); split2_f16(o.z, fs, h[2], m[2]); split2_f16(o.w, fs, h[3], m[3]);
@@ -918,7 +934,16 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_apply_kernel(const float* __r
       *reinterpret_cast<uint2*>(mid + off) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
       if (lo) *reinterpret_cast<uint2*>(lo + off) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
     }
+  };
+  // two elements per trip: both loads of the full-size map are in flight before the first store (175 MB in, 175 MB out at layer 1 of
+  // the depth encoder: 3.5 TB/s with one)
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 v0 = reinterpret_cast<const float4*>(x)[i], v1 = reinterpret_cast<const float4*>(x)[i + stride];
+    finish(i, v0);
+    finish(i + stride, v1);
   }
+  if (i < n4) finish(i, reinterpret_cast<const float4*>(x)[i]);
 }
 
 int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* x, int B, int H, int W, int C, int k,
@@ -928,7 +953,8 @@ int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* 
   const bool f16x2 = dy_planes && !dy_planes[2];
   DIC_REQUIRE(!f16x2 || (f16 && f16->bound && f16->slot), "bn_pool_backward: f16x2 planes need a scale slot");
   const long long rows = (long long)B * H * W;
-  const PoolGeom pg{H, W, k, H / k, W / k};
+  DIC_REQUIRE((long long)B * H * W * C / 4 < (1ll << 31) && 256 % (C / 4) == 0, "bn_pool_backward: index range / C <= 1024 with C / 4 dividing 256");
+  const PoolGeom pg{H, W, k, H / k, W / k, make_fastdiv((unsigned)H), make_fastdiv((unsigned)W), make_fastdiv((unsigned)k)};
   float* part = ws;
   float* k2 = ws + (size_t)kBnChunksMax * 2 * C;
   float* k3 = k2 + C;
@@ -942,7 +968,7 @@ int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* 
   const long long n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dpool, idx, x, dy, n4, C / 4, pg,
                      gamma, bn, k2, k3, dy_planes ? dy_planes[0] : nullptr, dy_planes ? dy_planes[1] : nullptr,
-                     dy_planes ? dy_planes[2] : nullptr, f16x2 ? (const float*)f16->slot : nullptr);
+                     dy_planes ? dy_planes[2] : nullptr, f16x2 ? (const float*)f16->slot : nullptr, make_fastdiv((unsigned)(C / 4)));
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -993,7 +1019,7 @@ __global__ void __launch_bounds__(256) colsum_rows_kernel(const float* __restric
 int colsum_rows(const float* X, long long ld, long long rows, int C, float* out, float* ws, hipStream_t st) {
   const bool v4 = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && rows >= 256;
   if (v4) {
-    const int chunks = reduce_chunks(C);                  // ws holds up to 256 x C partial rows
+    const int chunks = std::min(256, reduce_chunks(C));   // ws holds up to 256 x C partial rows
     hipLaunchKernelGGL(colsum_rows_v4_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, X, ld, rows, C, ws);
     hipLaunchKernelGGL(colsum_rows_kernel, dim3(ceil_div(C, 256), 1), dim3(256), 0, st, ws, (long long)C,
                        (long long)chunks, C, out, 1);

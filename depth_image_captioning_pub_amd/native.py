@@ -406,7 +406,20 @@ class ResNetRunner:
             ent = self.table[i]
             ent.w = w_ohwi.data_ptr()
             tens = [w, w_ohwi]
-            if self.mode >= 1 and i == 0 and (co, ci, k) == (64, 3, 7):
+            if self.mode == 2 and i == 0 and (co, ci, k) == (64, 3, 7):
+                # 7x7 stem in the f16x2 format (round 4): two strip-ordered fp16 planes of scale * w (dic_resnet_pack_stem_weights_f16x2)
+                import math
+                wmax = float(w.abs().max())
+                if not (wmax > 0.0 and math.isfinite(wmax)):
+                    raise _lib.DicError(f"{key}: f16x2 mode needs finite, non-zero weights")
+                scale = 2.0 ** math.floor(14 - math.log2(wmax))
+                scratch = torch.empty(64 * 224, dtype=torch.float32, device=w.device)
+                planes = [torch.empty(64 * 224, dtype=torch.int16, device=w.device) for _ in range(2)]
+                check(lib.dic_resnet_pack_stem_weights_f16x2(ptr(w), ptr(scratch), ptr(planes[0]), ptr(planes[1]), C.c_float(scale),
+                                                             stream_ptr()), "dic_resnet_pack_stem_weights_f16x2")
+                ent.w_hi, ent.w_mid, ent.w_lo, ent.w_scale = planes[0].data_ptr(), planes[1].data_ptr(), None, scale
+                tens += planes + [scratch]
+            elif self.mode >= 1 and i == 0 and (co, ci, k) == (64, 3, 7):
                 # 7x7 stem: strip-ordered weight planes [64][7][8][4] for the bf16x3 kernel (dic_resnet_pack_stem_weights)
                 scratch = torch.empty(64 * 224, dtype=torch.float32, device=w.device)
                 planes = [torch.empty(64 * 224, dtype=torch.int16, device=w.device) for _ in range(3)]

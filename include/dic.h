@@ -284,6 +284,10 @@ int dic_oihw_to_ohwi(const float* src, float* dst, int O, int I, int KH, int KW,
  * w_oihw: [64][3][7][7]; scratch_f32: 64*224 floats. */
 int dic_resnet_pack_stem_weights(const float* w_oihw, float* scratch_f32, uint16_t* w_hi, uint16_t* w_mid, uint16_t* w_lo,
                                  void* stream);
+/* Mode 2 (f16x2): the same strip-ordered stem weights as TWO fp16 planes of w_scale * w (w_scale: a power of two with
+ * max|w| * w_scale in (2^13, 2^14], like every mode-2 layer; layer 0 of the table then carries w_hi = w_h1, w_mid = w_h2, w_lo = NULL,
+ * w_scale).  The stem then packs the image as two guarded fp16 planes of 4 * x and runs three matrix-core products instead of six. */
+int dic_resnet_pack_stem_weights_f16x2(const float* w_oihw, float* scratch_f32, uint16_t* w_h1, uint16_t* w_h2, float w_scale, void* stream);
 int dic_resnet_num_layers(const int* blocks);
 size_t dic_resnet_workspace_bytes(int B, int H, int W, const int* blocks, int mode);
 /* imgs [B,3,H,W] NCHW -> features [B,196,2048].  train_bn=1 reproduces quirk Q1 of the reference
