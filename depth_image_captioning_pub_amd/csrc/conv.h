@@ -38,8 +38,9 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse = nullptr,
                        int* bn_fused = nullptr, int fmt = 0, float out_scale = 1.0f,
-                       unsigned* status = nullptr /* f16x2: overflow guard word (common.h) */);
-bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs);
+                       unsigned* status = nullptr /* f16x2: overflow guard word (common.h) */,
+                       const float* res_scale = nullptr, const float* res_shift = nullptr /* f16x2: BatchNorm of the residual itself */);
+bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs, int fmt = 0);
 // 3x3 / stride 1 / pad 1 convolution of 14x14 maps with the same fusion, in the LDS-halo kernel's producer waves (f16x2 format only);
 // returns 1 (nothing launched) for every other shape / format
 int conv3x3_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, int relu, const ConvDesc& d,

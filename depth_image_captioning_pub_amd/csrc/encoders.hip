@@ -258,7 +258,8 @@ static int conv_bn_bf3(unsigned short* const x_planes[3], const ConvDesc& d, con
 // gemm_bf3.hip) -> raw fp32 out + BN scale/shift in `bn`.  Returns 1 when the launch policy keeps the shape off that kernel (nothing
 // launched, nothing written).
 static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* res, float* act_out, const ConvDesc& d,
-                             const dic_conv_bn_layer& L, float* y, const RnWs& ws, int train_bn, hipStream_t st, const BnBuf& bn, int fmt) {
+                             const dic_conv_bn_layer& L, float* y, const RnWs& ws, int train_bn, hipStream_t st, const BnBuf& bn, int fmt,
+                             const BnBuf* res_bn = nullptr) {
   if (!(d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && d.C <= 2048)) return 1;
   int mtiles = 0, fused = 0;
   const unsigned short* wp[3] = {L.w_hi, L.w_mid, L.w_lo};
@@ -266,7 +267,8 @@ static int conv_bn_bf3_fused(const float* raw, const BnBuf& in_bn, const float* 
                       (double)d.M(), kBnEps, kBnMomentum, fmt ? ws.status : nullptr};
   const int rc = conv1x1_fwd_bf3_bn(raw, in_bn.scale, in_bn.shift, res, 1, act_out, d.M(), d.C, wp, d.CO, y, train_bn ? ws.partial : nullptr,
                                     &mtiles, ws.tail, kResnetTailSlabs, st, (train_bn && g_fused_tail_bn) ? &fa : nullptr, &fused, fmt,
-                                    fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f, fmt ? ws.status : nullptr);
+                                    fmt ? 1.0f / (kF16ActScale * L.w_scale) : 1.0f, fmt ? ws.status : nullptr,
+                                    res_bn ? res_bn->scale : nullptr, res_bn ? res_bn->shift : nullptr);
   if (rc != DIC_OK) return rc;
   if (train_bn && fused) return DIC_OK;
   if (train_bn)
@@ -296,6 +298,8 @@ static int conv_bn_bf3_astat(const float* raw, const BnBuf& in_bn, const ConvDes
 static int g_fuse_bn_operand_switch = -1;      // -1 (code 104, default): by operand format - both for bf16x3; block outputs only for f16x2, where the
                                                // matrix-core work per K tile is halved and conv3's eightfold re-transform of its input no longer hides
 void resnet_fuse_bn_operand(int mask) { g_fuse_bn_operand_switch = mask < 0 ? -1 : (mask & 3); }
+static int g_fuse_res_bn = 1;                  // codes 98 / 99: the downsample branch's BatchNorm applied to the residual inside the on-the-fly 1x1 kernel (f16x2): never / yes (default)
+void resnet_fuse_res_bn(int on) { g_fuse_res_bn = on; }
 static int g_fuse_bn_halo = 1;                 // codes 108 / 109: conv1's output (consumed by the 3x3 conv2) formed inside the LDS-halo kernel's producer waves: never / where
                                                // that kernel takes the shape (default; f16x2 format, 14x14 maps: 35 of ResNet-152's 50 blocks)
 void resnet_fuse_bn_halo(int on) { g_fuse_bn_halo = on; }
@@ -366,6 +370,7 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
   for (int s = 0; s < 4; ++s) {
     bool pending = false;                  // the block input is not materialised: it is relu(bn3(R3) + pend_res)
     const float* pend_res = nullptr;
+    const BnBuf* pend_res_bn = nullptr;    // ... where pend_res is a raw convolution output with this BatchNorm of its own (f16x2: the downsample branch)
     const float* in32_carry = nullptr;     // fp32 copy of the block input written by the previous block's output pass
     for (int b = 0; b < blocks[s]; ++b) {
       const RnConv& c1 = pl.convs[ci++];
@@ -375,9 +380,9 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       in32_carry = nullptr;
       if (pending) {
         float* in_b = IN[b & 1];
-        int rc = conv_bn_bf3_fused(R3, ws.bn3, pend_res, in_b, c1.d, layers[c1.layer], R1, ws, train_bn, st, ws.bn, fmt);
+        int rc = conv_bn_bf3_fused(R3, ws.bn3, pend_res, in_b, c1.d, layers[c1.layer], R1, ws, train_bn, st, ws.bn, fmt, pend_res_bn);
         if (rc == 1) {                      // shape not on the persistent kernel: form the input as planes (+ fp32) after all
-          DIC_BN_APPLY_PLANES_OUT(R3, pend_res, nullptr, in_b, Xp, c1.d.M(), c1.d.C, ws.bn3, 1, st, nullptr, guard);
+          DIC_BN_APPLY_PLANES_OUT(R3, pend_res, nullptr, in_b, Xp, c1.d.M(), c1.d.C, ws.bn3, 1, st, pend_res_bn, guard);
           rc = conv_bn_bf3(Xp, c1.d, layers[c1.layer], R1, ws, train_bn, st, nullptr, fmt);
         }
         DIC_TRY(rc);
@@ -417,10 +422,12 @@ static int resnet_fwd_bf3(const dic_conv_bn_layer* layers, const int* blocks, co
       // (decided here, by the next conv1's shape: a shape the persistent kernel does not take would pay for the fp32 copy on top of
       //  the planes)
       const bool next_fused = (g_fuse_bn_operand & 1) && b + 1 < blocks[s] && (b == 0 || in32) &&
-                              conv1x1_bf3_bn_eligible(c3.d.M(), c3.d.CO, c1.d.CO, kResnetTailSlabs);
+                              conv1x1_bf3_bn_eligible(c3.d.M(), c3.d.CO, c1.d.CO, kResnetTailSlabs, fmt);
       if (next_fused) {
         // left to the next block's conv1.  The downsample output is normalised in place first (the kernel adds a plain residual)
-        if (b == 0) DIC_TRY(bn_apply(Cf, nullptr, Cf, c3.d.M(), c3.d.CO, ws.bn_ds, 0, st));
+        // (f16x2: the kernel applies the branch's BatchNorm to the residual itself - switch 99; else an in-place pass over it first)
+        pend_res_bn = (b == 0 && fmt && g_fuse_res_bn) ? &ws.bn_ds : nullptr;
+        if (b == 0 && !pend_res_bn) DIC_TRY(bn_apply(Cf, nullptr, Cf, c3.d.M(), c3.d.CO, ws.bn_ds, 0, st));
         pend_res = b == 0 ? Cf : in32;
         pending = true;
         continue;

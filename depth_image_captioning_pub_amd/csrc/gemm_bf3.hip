@@ -114,6 +114,10 @@ struct Bf3Params {
   // (+ a_res[m][k])) - the BatchNorm-apply / residual / ReLU pass that would otherwise write it as planes; a_out (nullable)
   // receives the fp32 values once (tiles with tn == 0): the block output that is the next block's identity
   const float *a_raw, *a_scale, *a_shift, *a_res;
+  // f16x2 form of the 1x1 kernel only (nullable): the residual is itself a raw convolution output with a BatchNorm of its own (the
+  // downsample branch of a stage's first block): residual = a_res * a_res_scale[k] + a_res_shift[k], one fused multiply-add rounded to
+  // fp32 - what the in-place bn_apply pass over that branch used to leave in memory
+  const float *a_res_scale, *a_res_shift;
   float* a_out;
   long long a_ld;
   int a_relu;
@@ -505,6 +509,7 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];
   constexpr bool kBn = AK == OPK_ROWK_BN;
   __shared__ float bn_tab[kBn ? 2 * kBnTabMax : 1];      // scale | shift of the on-the-fly operand (144 + 16 KB = all of the LDS)
+  __shared__ float res_tab[(kBn && FMT == 1) ? 2 * kBnTabMax : 1];      // f16x2 (96 + 16 + 16 KB): scale | shift of the residual's own BatchNorm
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = (p.K + BK3 - 1) / BK3;
@@ -528,6 +533,10 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
   if (total == 0) return;
   if constexpr (kBn) {     // scale / shift of every input channel -> LDS (all eight waves; one barrier, once per launch)
     for (int k = tid; k < p.K; k += 256 + 64 * NPW) { bn_tab[k] = p.a_scale[k]; bn_tab[kBnTabMax + k] = p.a_shift[k]; }
+    if constexpr (FMT == 1) {
+      if (p.a_res_scale)
+        for (int k = tid; k < p.K; k += 256 + 64 * NPW) { res_tab[k] = p.a_res_scale[k]; res_tab[kBnTabMax + k] = p.a_res_shift[k]; }
+    }
     __syncthreads();
   }
 
@@ -550,6 +559,7 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
     __builtin_amdgcn_s_setprio(3);       // the transform's vector instructions ahead of the computing wave of the same SIMD (measured: no change
                                          // either way - the two instruction streams add up on the SIMD whatever their order)
     const bool has_res = p.a_res != nullptr;
+    const bool has_res_bn = has_res && p.a_res_scale != nullptr;
     typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
     // ---- slot iterators: (work item, K tile) of the next B slot to issue / next A slot to load / next A slot to transform
     struct It { int j, kt, k0, nk; };
@@ -648,6 +658,20 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
       typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
       float v[NR][4];
       const f32x2_ s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w}, t01 = {t4.x, t4.y}, t23 = {t4.z, t4.w};
+      if constexpr (FMT == 1) {
+        if (has_res_bn) {      // the residual's own BatchNorm first (wave-uniform branch): q <- fma(q, scale, shift), rounded to fp32
+          u32x4 rsq, rtq;
+          const unsigned rtab = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)res_tab + S.tab;
+          bf3_lds_read(rsq, rtab); bf3_lds_read(rtq, rtab + (unsigned)kBnTabMax * 4u);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rsq), "+v"(rtq)::"memory");
+          const float4 a4 = __builtin_bit_cast(float4, rsq), b4 = __builtin_bit_cast(float4, rtq);
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            S.rr[i].x = fmaf(S.rr[i].x, a4.x, b4.x); S.rr[i].y = fmaf(S.rr[i].y, a4.y, b4.y);
+            S.rr[i].z = fmaf(S.rr[i].z, a4.z, b4.z); S.rr[i].w = fmaf(S.rr[i].w, a4.w, b4.w);
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const f32x4_ x = S.ra[i], q = S.rr[i];
@@ -1525,6 +1549,7 @@ static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the 
 static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
 static int g_bf3_remainder_split = 1;  // persistent kernels: remainder-round K split on (default) / off (codes 91 / 90)
+static int g_bf3_narrow_bn = 1;        // on-the-fly-operand 1x1 kernel for 64 output channels (codes 96 / 97)
 static int g_bf3_halo28 = 1;           // 3x3 convolutions of 28x28 maps with the on-the-fly operand on the LDS-halo kernel (codes 94 / 95)
 static int g_bf3_few_remap = 1;        // few-tiles launches: slice z on XCD z (codes 92 / 93)
 static int g_bf3_wgrad_persist = 1;    // weight gradients with 32..255 output tiles of 128x128: on the persistent kernel, every tile in K slices (codes 118 / 119)
@@ -1576,7 +1601,8 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 112 || code == 113) { g_bf3_producers = code == 112 ? 4 : 8; return 0; }      // f16x2 on-the-fly-operand kernel: four / eight (default) producer waves
   if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }
   if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }
-  if (code == 94 || code == 95) { g_bf3_halo28 = code - 94; return 0; }                      // LDS-halo kernel for 28x28 maps (on-the-fly operand form): never / by policy (default)                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
+  if (code == 94 || code == 95) { g_bf3_halo28 = code - 94; return 0; }
+  if (code == 96 || code == 97) { g_bf3_narrow_bn = code - 96; return 0; }                   // on-the-fly-operand 1x1 kernel for CO = 64 (layer 1's conv1): never / by policy (default)                      // LDS-halo kernel for 28x28 maps (on-the-fly operand form): never / by policy (default)                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
   if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)          // ... its input slots in flight per producer wave: four (default) / six
 #ifdef DIC_EXPERIMENTS
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
@@ -1622,7 +1648,11 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // (row-major operands of the persistent kernels go through 32-bit buffer offsets: K in whole 32-element tiles, planes below 2 GiB)
   const bool buf_ok = p.K % BK3 == 0 && p.B.ld % 32 == 0 && (long long)(p.N + 1) * p.B.ld * 2 < (1ll << 31) &&
                       (p.A.kind != OPK_ROWK || (p.A.ld % 32 == 0 && (long long)(p.M + 1) * p.A.ld * 2 < (1ll << 31)));
-  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && p.N % 128 == 0 && (plain_ep || g_bf3_ws) && buf_ok;
+  // (64 output channels - ResNet layer 1's conv1 - only for the on-the-fly operand: the weight rows 64..127 of the 128-column tile are
+  //  out of the buffer's range and load as zeros, the epilogue's column guard drops them; twice the matrix work of a kernel that runs
+  //  at a seventh of the matrix pipe, in exchange for the 820-MB pass that would otherwise write that block output as planes)
+  const bool narrow_bn = g_bf3_narrow_bn != 0 && p.a_raw && p.N == 64 && p.A.kind == OPK_ROWK && p.fmt == 1;
+  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && (p.N % 128 == 0 || narrow_bn) && (plain_ep || g_bf3_ws) && buf_ok;
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
   double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
@@ -1640,7 +1670,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   int few_sp = 0;
   {
     const int gmax = g_bf3_remainder_grid, units = ceil_div(p.K, BK3);
-    if (g_bf3_remainder_split && tail_ws && splitk <= 1 && t22 >= 32 && t22 < gmax && units >= 32) {
+    if (g_bf3_remainder_split && tail_ws && splitk <= 1 && t22 >= 32 && t22 < gmax && units >= 32 && !narrow_bn) {
       int sp = std::min(std::min(std::min(gmax / (int)t22, units / 8), 16), tail_ws_slabs / 4 / (int)t22);
       while (sp > 1 && (sp - 1) * ceil_div(units, sp) >= units) --sp;
       if (sp >= 2 && t22 * sp >= 160) few_sp = sp;
@@ -1724,7 +1754,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       p.tail_first_tile = 0; p.tail_split = few_sp; p.tail_ws = tail_ws;
       p.few_remap = g_bf3_few_remap;
     } else
-    if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4) {
+    if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4 && !narrow_bn) {      // (the fix-up works on whole 64x64 quadrants of N % 128 == 0)
       // tail_ws holds tail_ws_slabs slabs of [64][64] floats (kGemmTailWsBytes = 256 for callers of the C ABI, 1024 inside the
       // ResNet workspace); a piece writes four (one per consumer wave): r * sp <= slabs / 4
       const int kSlabs = tail_ws_slabs;
@@ -1912,7 +1942,7 @@ int conv_fwd_bf3(const unsigned short* const x_planes[3], const ConvDesc& d, con
 // act_out (nullable) receives the fp32 input values once.  Returns DIC_OK, 1 when the launch policy would not run this shape on
 // that kernel (nothing launched: the caller takes the bn_apply_planes route), or a negative error.
 // would conv1x1_fwd_bf3_bn run this shape (the launch policy's answer, nothing launched)?
-bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs) {
+bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs, int fmt) {
   if (C % 32 != 0 || C > kBnTabMax || (long long)M * C * 4 >= (1ll << 32)) return false;
   static float dummy;                         // stands for "a tail workspace is there"; never dereferenced
   Bf3Params p{};
@@ -1920,6 +1950,7 @@ bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs) {
   p.A.kind = OPK_ROWK; p.A.ld = C; p.A.paired = 1;
   p.B.kind = OPK_ROWK; p.B.ld = C; p.B.paired = 1;
   p.a_raw = &dummy;
+  p.fmt = fmt;
   p.ep = ep_store(&dummy, CO, nullptr, ACT_NONE);
   return launch_bf3(p, nullptr, &dummy, 1, nullptr, nullptr, nullptr, tail_ws_slabs, true) == DIC_OK;
 }
@@ -1927,7 +1958,8 @@ bool conv1x1_bf3_bn_eligible(int M, int C, int CO, int tail_ws_slabs) {
 int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift, const float* res, int relu, float* act_out,
                        int M, int C, const unsigned short* const w_planes[3], int CO, float* y, float* bn_partial,
                        int* mtiles_out, float* tail_ws, int tail_ws_slabs, hipStream_t st, const BnFuseArgs* bn_fuse, int* bn_fused, int fmt,
-                       float out_scale, unsigned* status) {
+                       float out_scale, unsigned* status, const float* res_scale, const float* res_shift) {
+  DIC_REQUIRE(!res_scale || (fmt == 1 && res && res_shift), "conv1x1_fwd_bf3_bn: a BatchNorm on the residual needs the f16x2 format, the residual and both tables");
   DIC_REQUIRE(raw && scale && shift && y && C % 32 == 0 && C <= kBnTabMax, "conv1x1_fwd_bf3_bn: C %% 32 == 0, C <= 2048");
   if ((long long)M * C * 4 >= (1ll << 32)) {                // the kernel addresses the input with 32-bit byte offsets
     set_last_error("conv1x1 with on-the-fly BatchNorm operand: input of %d x %d floats exceeds 4 GiB (32-bit offsets); nothing was launched", M, C);
@@ -1939,6 +1971,7 @@ int conv1x1_fwd_bf3_bn(const float* raw, const float* scale, const float* shift,
   p.A.kind = OPK_ROWK; p.A.ld = C; p.A.paired = 1;
   p.B.kind = OPK_ROWK; p.B.ld = C; p.B.paired = 1;
   p.a_raw = raw; p.a_scale = scale; p.a_shift = shift; p.a_res = res; p.a_out = act_out; p.a_ld = C; p.a_relu = relu;
+  p.a_res_scale = res_scale; p.a_res_shift = res_shift;
   p.status = status;
   p.ep = ep_store(y, CO, nullptr, ACT_NONE);
   p.ep.stats = bn_partial;

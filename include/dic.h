@@ -433,6 +433,10 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *                wherever that kernel takes the shape (default)
  *   94 95        3x3 convolutions of 28x28 maps (layer 2) with that on-the-fly operand on the LDS-halo kernel: never (gathered kernel + planes
  *                pass) / by policy (default)
+ *   96 97        mode 2: the on-the-fly-operand 1x1 kernel also for 64 output channels (layer 1's conv1; half of its 128-column tile idle):
+ *                never (block output written as planes by a pass) / by policy (default)
+ *   98 99        mode 2: the downsample branch's own BatchNorm applied to the residual inside the on-the-fly-operand 1x1 kernel (no in-place
+ *                pass over that branch): never / yes (default)
  *   92 93        few-tiles launches (every output tile cut into K slices): plain workgroup order / K slice z on XCD z (default)
  *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
  *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
