@@ -1599,11 +1599,11 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 90 || code == 91) { g_bf3_remainder_split = code - 90; return 0; }      // remainder-round K split of the persistent kernels off / on (default)
   if (code == 80 || code == 81) { g_bf3_ws256 = code == 80; return 0; }              // 256x128 form for f16x2 1x1 convolutions: by policy (default) / never
   if (code == 112 || code == 113) { g_bf3_producers = code == 112 ? 4 : 8; return 0; }      // f16x2 on-the-fly-operand kernel: four / eight (default) producer waves
-  if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }
-  if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }
-  if (code == 94 || code == 95) { g_bf3_halo28 = code - 94; return 0; }
-  if (code == 96 || code == 97) { g_bf3_narrow_bn = code - 96; return 0; }                   // on-the-fly-operand 1x1 kernel for CO = 64 (layer 1's conv1): never / by policy (default)                      // LDS-halo kernel for 28x28 maps (on-the-fly operand form): never / by policy (default)                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
-  if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)          // ... its input slots in flight per producer wave: four (default) / six
+  if (code == 114 || code == 115) { g_bf3_slots = code == 114 ? 4 : 6; return 0; }          // ... its input slots in flight per producer wave: four (default) / six
+  if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
+  if (code == 94 || code == 95) { g_bf3_halo28 = code - 94; return 0; }                      // LDS-halo kernel for 28x28 maps (on-the-fly operand form): never / by policy (default)
+  if (code == 96 || code == 97) { g_bf3_narrow_bn = code - 96; return 0; }                   // on-the-fly-operand 1x1 kernel for CO = 64 (layer 1's conv1): never / by policy (default)
+  if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)
 #ifdef DIC_EXPERIMENTS
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
