@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) bn_ema_update_kernel(float* __restrict__ 
                                                              long long n, float keep, const unsigned* __restrict__ skip_if_raised) {
   if (skip_if_raised && *skip_if_raised != 0u) return;       // f16x2 overflow guard (dic.h): a flagged forward's statistics are dropped
   const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) running[i] = keep * running[i] + delta[i];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) running[i] = fmaf(keep, running[i], delta[i]);
 }
 
 }  // namespace dic

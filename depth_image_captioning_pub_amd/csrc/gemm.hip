@@ -601,8 +601,8 @@ __global__ void __launch_bounds__(1024) tail_fixup_bn_kernel(const GemmParams p,
     if (!finite) f16x2_raise(bn.status, 8u);
     if (bn.running_mean && finite) {
       const double unb = bn.count > 1.0 ? var * bn.count / (bn.count - 1.0) : var;
-      bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
-      bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unb;
+      bn.running_mean[c] = fmaf(1.f - bn.momentum, bn.running_mean[c], __fmul_rn(bn.momentum, (float)mean));      // (form: bn_finalize_train_kernel, nn_kernels.hip)
+      bn.running_var[c] = fmaf(1.f - bn.momentum, bn.running_var[c], __fmul_rn(bn.momentum, (float)unb));
     }
   }
 }
