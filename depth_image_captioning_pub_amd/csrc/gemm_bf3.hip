@@ -970,21 +970,163 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
 // for (scripts/bench_bf3_ws_ablate.py: 3100-3900 cycles per K tile against 2400-2600 without any DMA).  Two ring stages of
 // 72 KB; B fragments are single-buffered (the second computing wave of the SIMD covers their latency), A fragments stay
 // double-buffered by k-step.  BatchNorm partials per 64-row wave tile: [4*mtiles][2][N].  Bit-identical to gemm_bf3_kernel.
-template <int AK, int FMT = 0>
+// BNA (round 4, f16x2 only; PARKED - instantiated in the experiments build only, switch 107): built, bit-identical to the plane route on
+// every conv3 shape of the network (scripts/experiments/test_parked_kernels_gpu.py), and neutral: 35.3 us per layer-3 launch against
+// 28.6 + 6.3 us for the plane kernel and the bn_apply_planes pass it replaces, pipelined step 9.03 ms with conv3 folded onto it and
+// 9.03 ms without (the 12.8-MB tensors between conv2 and conv3 never leave the Infinity Cache: removing their passes removes no HBM
+// traffic - unlike the 51-MB block boundary, where bytes came off the step one for one).
+// The A operand is formed on the fly, A(m,k) = act(a_raw[m][k] * a_scale[k] + a_shift[k]) - conv3 reading the
+// RAW output of conv2, its BatchNorm-apply + ReLU + split done by the four producer waves (no residual, no fp32 copy: those belong to
+// the block boundary and stay on the 128x128 kernel).  Thread (r8, kq) of producer wave pw holds channels 4*kq .. 4*kq+3 of the rows
+// pw*64 + 8*i + r8, i < 8, of the 256 x 32 tile; three register sets: a load has two K-tile periods to arrive.  Slot protocol = the
+// on-the-fly form of gemm_bf3_persist_ws_kernel (iteration g: L(g+1), D(g+1) done -> transform slot g+1 -> barrier g -> D(g+3),
+// L(g+4)); the weight tiles stream by LDS-DMA as before.
+constexpr int kWs256BnTab = 512;      // channels of the on-the-fly operand of the 256x128 kernel (scale | shift table in LDS)
+template <int AK, int FMT = 0, bool BNA = false>
 __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Params p) {
+  static_assert(!BNA || (FMT == 1 && AK == OPK_ROWK), "on-the-fly operand of the 256x128 kernel: f16x2, row-major");
   constexpr int BM = 256, BN = 128;
   constexpr int NPL = Bf3Fmt<FMT>::NPL;
   constexpr int NST = NPL == 2 ? 3 : 2;                            // ring stages: 3 x 48 KB (two planes per operand) or 2 x 72 KB
   constexpr int APLANE = BM * BK3, BPLANE = BN * BK3, AOPER = NPL * APLANE, BOPER = NPL * BPLANE, STAGE = AOPER + BOPER;
   constexpr int NDMA = NPL * (BM / 64) + NPL * (BN / 64);         // 18 | 12 DMA instructions per producer wave and K tile
   __shared__ __align__(1024) unsigned short smem[NST * STAGE];     // 144 KB
+  __shared__ float bn_tab256[BNA ? 2 * kWs256BnTab : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = (p.K + BK3 - 1) / BK3;
   const int T = p.mtiles * p.ntiles, G = gridDim.x;
   const int ntl = (T - (int)blockIdx.x + G - 1) / G;
   const int total = ntl * nkt;
+  if constexpr (BNA) {     // scale / shift of every input channel -> LDS (all twelve waves; one barrier, once per launch)
+    for (int k = tid; k < p.K; k += 768) { bn_tab256[k] = p.a_scale[k]; bn_tab256[kWs256BnTab + k] = p.a_shift[k]; }
+    __syncthreads();
+  }
 
+  if constexpr (BNA) {
+  if (wave >= 8) {
+    // ---------------- producer waves, on-the-fly A operand
+    constexpr int NR = 8, DA = 3, NB = 2 * NPL;      // rows per thread, register sets, weight-DMA instructions per wave and slot
+    const int pt = tid - 512, prow0 = (pt >> 6) * 64 + ((pt & 63) >> 3), kq = pt & 7;
+    typename Bf3LoaderFor<OPK_ROWK, BN, NPL>::type lbld;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    struct ASet { f32x4_ ra[NR]; unsigned tab, flg; };      // flg: bits 0..7 row i inside the matrix, bit 8 ragged tile (wave-uniform)
+    ASet sets[DA];
+    // slot iterators: slot s = (tile s / nkt of this workgroup, K tile s % nkt)
+    int bj = 0, bkt = 0, lj = 0, lkt = 0;
+    auto tile_id = [&](int j) { return xcd_remap(blockIdx.x + j * G, T); };
+    { const int t = tile_id(0); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); }
+    auto issue_b = [&](unsigned short* stage) {
+      lbld.issue(bkt * BK3, stage + AOPER);
+      if (++bkt == nkt) { bkt = 0; if (++bj < ntl) { const int t = tile_id(bj); lbld.init(p.B, (t % p.ntiles) * BN, p.N, p.K); } }
+    };
+    const unsigned ldb = (unsigned)p.a_ld * 4u;
+    unsigned lrow[NR], lflg = 0;
+    auto load_tile = [&]() {
+      const int t = tile_id(lj), tm = t / p.ntiles;
+      const int gr = tm * BM + prow0;
+      lflg = (tm * BM + BM > p.M) ? 256u : 0u;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        lflg |= (gr + 8 * i < p.M) ? (1u << i) : 0u;
+        lrow[i] = (unsigned)min(gr + 8 * i, p.M - 1) * ldb + (unsigned)kq * 16u;
+      }
+    };
+    load_tile();
+    auto load_a = [&](ASet& S) {
+      const unsigned kb = (unsigned)lkt * (BK3 * 4u);
+      S.tab = kb + (unsigned)kq * 16u; S.flg = lflg;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const unsigned vo = lrow[i] + kb;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.ra[i]) : "v"(vo), "s"(p.a_raw) : "memory");
+      }
+      if (++lkt == nkt) { lkt = 0; if (++lj < ntl) load_tile(); }
+    };
+    unsigned doff[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const unsigned r = (unsigned)(prow0 + 8 * i);
+      doff[i] = r * 64u + ((((unsigned)kq >> 1) ^ ((r >> 2) & 3u)) << 4) + ((unsigned)kq & 1u) * 8u;
+    }
+    const float relu_floor = p.a_relu ? 0.f : -__builtin_inff();
+    auto transform = [&](ASet& S, unsigned short* stage) {
+      u32x4 scq, shq;
+      const unsigned tab = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)bn_tab256 + S.tab;
+      bf3_lds_read(scq, tab); bf3_lds_read(shq, tab + (unsigned)kWs256BnTab * 4u);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(scq), "+v"(shq)::"memory");
+      const float4 s4 = __builtin_bit_cast(float4, scq), t4 = __builtin_bit_cast(float4, shq);
+      const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)stage;
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+      const f32x2_ s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w}, t01 = {t4.x, t4.y}, t23 = {t4.z, t4.w};
+      const bool ragged = __builtin_amdgcn_readfirstlane(S.flg) & 256u;
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const f32x4_ x = S.ra[i];
+        const f32x2_ a01 = f32x2_{x.x, x.y} * s01 + t01, a23 = f32x2_{x.z, x.w} * s23 + t23;      // packed fp32 fma
+        float v[4] = {fmaxf(a01.x, relu_floor), fmaxf(a01.y, relu_floor), fmaxf(a23.x, relu_floor), fmaxf(a23.y, relu_floor)};
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+        if (ragged && !((S.flg >> i) & 1u)) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }      // rows past the end of the matrix are zero
+        u32x2_ q1, q2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x2_ xx = f32x2_{v[2 * u], v[2 * u + 1]} * kF16ActScale;
+          const f16x2_ h1 = __builtin_convertvector(xx, f16x2_);
+          const f32x2_ r1 = xx - __builtin_convertvector(h1, f32x2_);
+          q1[u] = __builtin_bit_cast(unsigned, h1); q2[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f16x2_));
+        }
+        const unsigned dst = sbase + doff[i];
+        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(q1) : "memory");
+        asm volatile("ds_write_b64 %0, %1 offset:%c2" ::"v"(dst), "v"(q2), "i"(APLANE * 2) : "memory");
+      }
+      if (!(mx <= kF16Max / kF16ActScale)) f16x2_raise(p.status, 4u);      // overflow guard (common.h): NaN included
+    };
+    // ---- prologue: B slots 0..2 and A slots 0..DA-1 in flight; slot 0 transformed; then A slot DA
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0)
+      if (s0 < total) issue_b(smem + s0 * STAGE);
+#pragma unroll
+    for (int s0 = 0; s0 < DA; ++s0)
+      if (s0 < total) load_a(sets[s0]);
+    const bool steady_ok = total >= 2 * DA + 2;
+#define DIC_PIN_SLOT(S_)                                                                                                          \
+  do { _Pragma("unroll") for (int i_ = 0; i_ < NR; ++i_) asm volatile("" : "+v"((S_).ra[i_]) :: "memory"); } while (0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DIC_PIN_SLOT(sets[0]);
+    transform(sets[0], smem);
+    if (DA < total) load_a(sets[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // slot 0 is in LDS
+    int st = 0;
+    for (int g0 = 0; g0 < total; g0 += DA) {
+#pragma unroll
+      for (int u = 0; u < DA; ++u) {
+        const int g = g0 + u;
+        if (g >= total) break;
+        const int stn = st == NST - 1 ? 0 : st + 1;
+        if (g + 1 < total) {
+          // D(g+1) and L(g+1) must have landed; younger in issue order: L(g+2), D(g+2), L(g+3) (see the header)
+          if (steady_ok && g >= 2 && g + DA < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NR + NB) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          DIC_PIN_SLOT(sets[(u + 1) % DA]);
+          transform(sets[(u + 1) % DA], smem + stn * STAGE);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                              // slot g+1 is in LDS; the consumers are done with stage st
+        if (g + NST < total) issue_b(smem + st * STAGE);
+        if (g + 1 + DA < total) load_a(sets[(u + 1) % DA]);
+        st = stn;
+      }
+    }
+#undef DIC_PIN_SLOT
+    return;
+  }
+  } else
   if (wave >= 8) {
     // ---------------- producer waves (8..11 -> row groups 0..3 of the loaders)
     typename Bf3LoaderFor<AK, BM, NPL>::type la;
@@ -1560,6 +1702,7 @@ static int g_bf3_slots = 4;            // codes 114 / 115: input slots in flight
                                        //  asm load is garbage - that build hung the kernel; build.py now refuses any spilling kernel)
 static int g_bf3_producers = 8;        // codes 112 / 113: producer waves of the f16x2 on-the-fly-operand kernel: 4 / 8 (default)
 #ifdef DIC_EXPERIMENTS
+static int g_bf3_ws256_bn = 0;         // parked: on-the-fly operand (no residual, no copy) on the 256x128 kernel (codes 106 / 107)
 static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_ablate = 0;           // 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
@@ -1605,6 +1748,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 96 || code == 97) { g_bf3_narrow_bn = code - 96; return 0; }                   // on-the-fly-operand 1x1 kernel for CO = 64 (layer 1's conv1): never / by policy (default)
   if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)
 #ifdef DIC_EXPERIMENTS
+  if (code == 106 || code == 107) { g_bf3_ws256_bn = code - 106; return 0; }        // parked: conv3-style on-the-fly operand (no residual, no copy) on the 256x128 kernel: never (default) / by policy
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
@@ -1692,7 +1836,13 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     const long long t42 = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128);
     const int rounds42 = (int)((t42 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
     const double fill42 = (double)t42 / ((double)rounds42 * g_bf3_persist_grid);
-    if (g_bf3_force == 0 && g_bf3_ws256 != 0 && p.fmt == 1 && !p.a_raw && p.A.kind == OPK_ROWK && persist && few_sp == 0 && g_bf3_ws && plain_ep &&
+    // (with the on-the-fly operand - round 4, switch 107: conv3 reading conv2's raw output - only without residual / fp32 copy)
+#ifdef DIC_EXPERIMENTS      // parked (see the kernel's header): correct, bit-identical to the plane route, neutral in the step
+    const bool bna_ok = !p.a_raw || (g_bf3_ws256_bn != 0 && !p.a_res && !p.a_out && p.K >= 128 && p.K <= kWs256BnTab);
+#else
+    const bool bna_ok = !p.a_raw;
+#endif
+    if (g_bf3_force == 0 && g_bf3_ws256 != 0 && p.fmt == 1 && bna_ok && p.A.kind == OPK_ROWK && persist && few_sp == 0 && g_bf3_ws && plain_ep &&
         t42 >= 192 && fill42 >= 0.75 && p.K >= 64)
       ws256 = true;
 #ifdef DIC_EXPERIMENTS
@@ -1769,7 +1919,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     }
   }
   const bool halo_bna = halo && p.a_raw && p.fmt == 1 && !p.a_res && !p.a_out && cg.C <= kHaloBnTab && g_bf3_ablate == 0;      // 3x3 halo kernel with the on-the-fly operand
-  if (p.a_raw && !halo_bna && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) {      // on-the-fly operand: persistent 1x1 kernel, the halo kernel, or nothing
+  const bool ws256_bna = ws256 && persist && !halo && p.a_raw != nullptr;
+  if (p.a_raw && !halo_bna && !ws256_bna && !(persist && !halo && !ws256 && g_bf3_ws && g_bf3_ablate == 0 && !im)) {      // on-the-fly operand: persistent 1x1 kernel, the halo kernel, or nothing
     if (!probe && !im)      // (a caller that gets 1 takes the plane route; one that cannot - dic_debug_conv1x1_bn* - reports this text)
       set_last_error("conv1x1 with on-the-fly BatchNorm operand: shape M=%d C=%d -> CO=%d is not eligible (the launch policy keeps it off "
                      "the persistent 128x128 kernel: needs CO %% 128 == 0, C %% 32 == 0, C > 32 and enough output tiles to fill the CUs); "
@@ -1814,6 +1965,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     p.mtiles = ceil_div(p.M, 256); p.ntiles = ceil_div(p.N, 128);
     g_last_mtiles = ceil_div(p.M, 64);     // statistics rows per 64-row wave tile
     const int T4 = p.mtiles * p.ntiles, grid = ceil_div(T4, ceil_div(T4, g_bf3_persist_grid));
+#ifdef DIC_EXPERIMENTS
+    if (ws256_bna) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, true>), dim3(grid), dim3(768), 0, st, p);
+    else
+#endif
     if (p.fmt == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1>), dim3(grid), dim3(768), 0, st, p);
 #ifdef DIC_EXPERIMENTS
     else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_IM2COL>), dim3(grid), dim3(768), 0, st, p);

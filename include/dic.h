@@ -444,7 +444,7 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   118 119      weight gradients whose output is 32..255 tiles of 128x128 (the depth encoder's two): 64x64 tiles with the caller's K
  *                split / persistent warp-specialised kernel with every tile cut into K slices (default)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /
- * 256x128 contraction forms, the A-stationary conv3 kernel of round 4, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
+ * 256x128 contraction forms, the A-stationary conv3 kernel and the 256x128 kernel's on-the-fly-operand form of round 4, persistent decoder loop, packed-fp32 defect reproducer) are compiled only into the experiments
  * library (python -m depth_image_captioning_pub_amd.build --experiments -> libdic_experiments.so, -DDIC_EXPERIMENTS; codes
  * listed in csrc/api.hip and csrc/gemm_bf3.hip); scripts/ load it with DIC_LIB=experiments, the product never does.
  * bf16x3 key of dic_profile_end: 2000 (f16x2 operand format: 3000) + 10*A_kind (6 = on-the-fly BatchNorm operand) + t, t = 2*(tile_m/64 - 1) + (tile_n/64 - 1) for the plain tiles,

@@ -202,3 +202,60 @@ def test_resnet_forward_conv3_on_the_a_stationary_kernel_matches_plane_route(lib
     assert dy < 2e-3 and ds < 1e-4, (dy, ds)
 
 
+@pytest.mark.parametrize("M,Cin,CO", [(12544, 256, 1024), (50176, 128, 512), (3136, 512, 2048), (12500, 256, 1024), (12544, 256, 256)])
+def test_conv1x1_on_the_fly_operand_on_the_256x128_kernel(lib, M, Cin, CO):
+    """Round 4: conv3 reading conv2's RAW output - relu(raw * scale + shift), no residual, no fp32 copy - on the twelve-wave 256x128
+    kernel, its four producer waves forming the two fp16 plane images (switch 107; PARKED: neutral in the step) instead of the 128x128 kernel's (106):
+    same element-wise arithmetic, same products in the same order as the same kernel fed with planes -> bit-identical to that route
+    (the 128x128 kernel may cut its remainder tiles into K slices: rounding level), BatchNorm partial sums of the same totals; fp64; a ragged last tile (12500 rows), the guard, and a shape the policy keeps on the 128x128 kernel
+    (256 output channels: too few 256x128 tiles)."""
+    g = torch.Generator().manual_seed(M + Cin + CO)
+    raw = torch.randn(M, Cin, generator=g).to(DEV)
+    scale = (torch.rand(Cin, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cin, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(CO, Cin, generator=g) / Cin ** 0.5).to(DEV)
+    act = torch.relu((raw.double() * scale.double() + shift.double()).float())
+    w_scale = 2.0 ** math.floor(14 - math.log2(float(w.abs().max())))
+    wp = [torch.zeros((CO + 1) // 2 * 2 * Cin, dtype=torch.int16, device=DEV) for _ in range(2)]
+    check(lib.dic_split_f16x2_paired(ptr(w), C.c_longlong(CO), Cin, C.c_float(w_scale), ptr(wp[0]), ptr(wp[1]), stream_ptr()), "split w")
+    wpl = (C.c_void_p * 3)(wp[0].data_ptr(), wp[1].data_ptr(), None)
+    tail = torch.empty(1024 * 64 * 64, device=DEV)
+    out = {}
+    try:
+        for code in (106, 107, 107):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            y = torch.full((M, CO), float("nan"), device=DEV)
+            part = torch.zeros((M // 64 + 2) * 2 * CO, device=DEV)
+            mt = C.c_int(0)
+            rc = lib.dic_debug_conv1x1_bn_fmt(ptr(raw), ptr(scale), ptr(shift), None, 1, None, M, Cin, wpl, CO, ptr(y), ptr(part), C.byref(mt),
+                                              ptr(tail), 1024, 1, C.c_float(1.0 / (4.0 * w_scale)), stream_ptr())
+            assert rc == 0, (rc, lib.dic_last_error())
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all()
+            st = part[: mt.value * 2 * CO].view(mt.value, 2, CO).double().sum(0).cpu()
+            if code in out:
+                assert torch.equal(out[code][0], y), "repeated launch differs"
+            out[code] = (y, st)
+        # the plane route: the same 256x128 kernel fed with planes of the activation (same LDS image, same products in the same order)
+        xp = [torch.zeros((M + 1) // 2 * 2 * Cin, dtype=torch.int16, device=DEV) for _ in range(2)]
+        check(lib.dic_split_f16x2_paired(ptr(act), C.c_longlong(M), Cin, C.c_float(4.0), ptr(xp[0]), ptr(xp[1]), stream_ptr()), "split x")
+        y_pl = torch.full((M, CO), float("nan"), device=DEV)
+        check(lib.dic_debug_conv_fmt((C.c_void_p * 3)(xp[0].data_ptr(), xp[1].data_ptr(), None), 1, 1, M, Cin, wpl, CO, 1, 1, 0, ptr(y_pl), None, None,
+                                     ptr(tail), 1, C.c_float(1.0 / (4.0 * w_scale)), stream_ptr()), "planes")
+        torch.cuda.synchronize()
+    finally:
+        lib.dic_debug_force_staged_gemm(106)
+    ndiff = int((out[107][0] != y_pl).sum())         # (a double-rounded activation element of the torch evaluation would show in its CO outputs)
+    print(f"\noutputs that differ from the plane route: {ndiff} of {M * CO}")
+    assert ndiff <= 3 * CO and float((out[107][0] - y_pl).abs().max()) <= 2e-6 * float(y_pl.abs().max())
+    # the 128x128 kernel takes some of these shapes with the remainder-round K split: another association of the same products
+    assert float((out[106][0] - out[107][0]).abs().max()) <= 4e-6 * float(y_pl.abs().max())
+    ref64 = act.double().cpu() @ w.double().cpu().t()
+    sc = float(ref64.abs().max())
+    err = float((out[107][0].double().cpu() - ref64).abs().max()) / sc
+    print(f"\n{M}x{CO}x{Cin} on-the-fly operand, 256x128 kernel: max err / scale vs fp64 {err:.2e}")
+    assert err < 4e-6
+    for code in (106, 107):      # the partial sums are those of the stored fp32 outputs (per-tile fp32 sums: tolerance grows with the rows)
+        yd, st = out[code][0].double().cpu(), out[code][1]
+        tol = 1e-4 * sc * max(1.0, M / 12544)
+        assert torch.allclose(st[0], yd.sum(0), rtol=1e-5, atol=tol) and torch.allclose(st[1], (yd * yd).sum(0), rtol=1e-5, atol=tol)

@@ -94,7 +94,7 @@ def test_unknown_debug_switch_is_rejected():
     decoder loop, 1 register-staged kernel everywhere) belong to the experiments build.  No GPU call involved."""
     lib = ctypes.CDLL(build.build())
     lib.dic_last_error.restype = ctypes.c_char_p
-    for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 121, 110, 111):
+    for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 121, 110, 111, 106, 107):
         assert lib.dic_debug_force_staged_gemm(code) != 0, code
         assert b"unknown" in lib.dic_last_error()
     for code in (11, 21, 24, 70, 75, 74, 90, 81, 100, 101, 102, 103, 112, 115, 116, 118, 108, 92, 94, 96, 98, 20, 78, 76, 73, 79, 91, 104, 80, 113, 114, 117, 119, 109, 93, 95, 97, 99):  # (ending on the defaults)
@@ -127,4 +127,5 @@ def test_product_library_holds_no_parked_or_probe_code():
         assert needle not in out, needle
     # the 256x128 twelve-wave kernel left the parked set in round 3 - in one instantiation: row-major operands, f16x2 format
     ws256 = sorted({w for w in out.split() if "ws256" in w})
-    assert ws256 and all(w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1EEEvNS_9Bf3ParamsE") for w in ws256), ws256
+    # (the product holds exactly the plain f16x2 row-major instantiation; the on-the-fly-operand form of round 4 is parked)
+    assert ws256 and all(w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1ELb0EEEvNS_9Bf3ParamsE") for w in ws256), ws256
