@@ -90,6 +90,10 @@ int conv1_depth_fwd_blocks(const ConvDesc& d);
 bool conv1_depth_supported(const ConvDesc& d);   // shape fits (rows <= 640 floats wide) and not switched off (debug code 130);
                                                   // otherwise the caller uses the generic gather kernels
 size_t conv1_depth_wgrad_ws_floats(const ConvDesc& d);
+// the whole backward of that layer (BatchNorm + ReLU + max-pool 3 behind the convolution) without the full-size gradient: depth_layer1.hip
+struct BnBuf;
+bool depth_layer1_sparse_supported(const ConvDesc& d);
+size_t depth_layer1_sparse_ws_floats(const ConvDesc& d);
 int conv1_depth_wgrad(const float* x, const ConvDesc& d, const float* dy, float* dw, float* dbias, float* ws, float* cs_ws,
                       hipStream_t st);
 // dW[CO][KH][KW][C] = sum_m dY[m,co] * patch(m)[kh,kw,c]   (split over M with workspace `ws`)

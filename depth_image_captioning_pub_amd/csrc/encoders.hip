@@ -37,6 +37,11 @@ static DepthGeom depth_geom(int B, int H, int W) {
   return g;
 }
 
+static int g_l1_sparse = 1;        // codes 180 / 181: backward of the depth encoder's first layer: dense passes over its 175-MB map / sparse (default)
+void depth_encoder_l1_sparse(int on) { g_l1_sparse = on; }
+int depth_layer1_backward_sparse(const float* depth, const ConvDesc& d, const float* dpool, const unsigned char* idx, const float* xsel,
+                                 const float* conv_w, const float* conv_b, const float* gamma, BnBuf bn, float* dgamma, float* dbeta,
+                                 float* dW, float* db, float* bn_ws, float* ws, float* cs_ws, hipStream_t st);      // depth_layer1.hip
 static int g_depth_f16x2 = 1;      // codes 116 / 117: conv2 / conv3 of the depth encoder in bf16x3 / f16x2 (default) arithmetic
 void depth_encoder_f16x2(int on) { g_depth_f16x2 = on; }
 constexpr int kWg1Split = 128;   // split-K of the conv1 weight gradient (K = B*73*73)
@@ -49,6 +54,7 @@ struct DepthWs {
   unsigned* bounds;                  // f16x2 scales chosen on the device (F16Scale, nn_kernels.h): bound words 0 w2, 1 w3, 2 dy3, 3 dy2
   float* slots;                      // ... and their {s, 1 / s} slots (2 floats each, same order)
   float *x1, *y1p, *x2, *y2p, *x3, *partial;
+  float* x1sel;                      // conv1's raw output at the argmax of every pooling window (sparse backward of layer 1, depth_layer1.hip)
   double* red;
   unsigned char *idx1, *idx2;
   BnBuf bn1, bn2, bn3;
@@ -79,6 +85,7 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   w.x1 = c.take<float>((size_t)g.M1 * 128);
   w.y1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
   w.idx1 = c.take<unsigned char>((size_t)B * g.P1h * g.P1w * 128);
+  w.x1sel = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
   w.x2 = c.take<float>((size_t)g.M2 * 512);
   w.y2p = c.take<float>((size_t)B * g.P2h * g.P2w * 512);
   w.idx2 = c.take<unsigned char>((size_t)B * g.P2h * g.P2w * 512);
@@ -91,7 +98,7 @@ static DepthWs depth_carve(void* p, size_t bytes, const DepthGeom& g, bool* ov) 
   w.red = c.take<double>(std::max(std::max(bn_finalize_ws_doubles((int)rows1, 128), bn_finalize_ws_doubles(g.M2 / 64 + 2, 512)),
                                    bn_finalize_ws_doubles(g.M3 / 64 + 2, 2048)));
   w.bn1 = take_bn(c, 128); w.bn2 = take_bn(c, 512); w.bn3 = take_bn(c, 2048);
-  w.dy1 = c.take<float>((size_t)g.M1 * 128);
+  w.dy1 = c.take<float>(std::max((size_t)g.M1 * 128, depth_layer1_sparse_supported(g.c1) ? depth_layer1_sparse_ws_floats(g.c1) : (size_t)0));      // (dense gradient of layer 1, or the scratch of its sparse backward)
   w.dy1p = c.take<float>((size_t)B * g.P1h * g.P1w * 128);
   w.dy2 = c.take<float>((size_t)g.M2 * 512);
   w.dy2p = c.take<float>((size_t)B * g.P2h * g.P2w * 512);
@@ -564,7 +571,7 @@ static int depth_encoder_fwd_impl(const dic_depth_encoder_weights* w, const dic_
     DIC_TRY(conv_fwd(depth, g.c1, w->conv1_w, w->conv1_b, ws.x1, train ? ws.partial : nullptr, &mt, st));
   if (train) DIC_TRY(bn_finalize_train(ws.partial, mt, g.M1, 128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, ws.red, st));
   else DIC_TRY(bn_finalize_eval(128, w->bn1_w, w->bn1_b, s->rm1, s->rv1, ws.bn1, st));
-  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st, y1p_out, ws.status));
+  DIC_TRY(bn_relu_maxpool(ws.x1, B, g.H1, g.W1, 128, &ws.bn1, 1, 3, 3, 0, ws.y1p, ws.idx1, st, y1p_out, ws.status, ws.x1sel));
   // conv2 (128->512, k3) + BN + ReLU + maxpool3            (:21-22,40-43)
   //   on the bf16x3 kernel (fp32-accurate, ~1.4x the exact-fp32 MFMA rate): split the pooled activations and W2
   {
@@ -646,6 +653,9 @@ static int depth_encoder_bwd_impl(const dic_depth_encoder_weights* w, const floa
     DIC_TRY(conv_dgrad_s1_bf3(dp, g.c2, wp, ws.dy1p, st, ws.tail, kResnetTailSlabs, fmt, fmt ? s_dy2.slot + 1 : nullptr, fmt ? inv_w2 : nullptr));
   }
   // layer 1 (no data gradient: the depth map is detached, depth_train.py:204)
+  if (g_l1_sparse && depth_layer1_sparse_supported(g.c1))      // round 4: no full-size gradient, no pass over x1 (depth_layer1.hip; switch 181)
+    return depth_layer1_backward_sparse(depth, g.c1, ws.dy1p, ws.idx1, ws.x1sel, w->conv1_w, w->conv1_b, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,
+                                        gr->conv1_w, gr->conv1_b, ws.bn_ws, ws.dy1, ws.cs_ws, st);
   DIC_TRY(bn_pool_backward(ws.dy1p, ws.idx1, ws.x1, B, g.H1, g.W1, 128, 3, w->bn1_w, ws.bn1, gr->bn1_w, gr->bn1_b,
                            ws.bn_ws, ws.dy1, st));
   if (conv1_depth_supported(g.c1)) {

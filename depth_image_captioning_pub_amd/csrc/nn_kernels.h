@@ -50,7 +50,8 @@ int bn_apply_planes(const float* x, const float* residual, const unsigned short*
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
                     float* y, unsigned char* idx, hipStream_t st,
                     unsigned short* const planes[3] = nullptr   /* optional: also/only paired bf16x3 planes (y may be null then) */,
-                    unsigned* status = nullptr)                  /* f16x2 planes: overflow guard word */;
+                    unsigned* status = nullptr                  /* f16x2 planes: overflow guard word */,
+                    float* xsel = nullptr                        /* optional [B,PH,PW,C]: the RAW x at each window's argmax (depth_layer1.hip) */);
 // y[0..n) = NaN if *status != 0 (the loud end of the f16x2 overflow guard: one small launch, returns at once otherwise)
 int poison_if_raised(float* y, long long n, const unsigned* status, hipStream_t st);
 int clear_status(unsigned* status, hipStream_t st);      // status[0..63] = 0 (a kernel: see nn_kernels.hip for why not a memset)
@@ -77,6 +78,10 @@ int bn_pool_backward(const float* dpool, const unsigned char* idx, const float* 
                      const float* gamma, BnBuf bn, float* dgamma, float* dbeta, float* ws, float* dy, hipStream_t st,
                      unsigned short* const dy_planes[3] = nullptr   /* optional: dy also as paired bf16x3 planes (f16x2 when [2] == NULL) */,
                      F16Scale* f16 = nullptr)                        /* f16x2 planes: the device-resident scale slot this call fills and uses */;
+// (pieces of bn_backward for a caller that forms the partial sums itself - depth_layer1.hip: layout of that workspace, and the finalize
+//  [chunks][2][C] partials -> dgamma, dbeta, k2 = mean(g), k3 = mean(g * xhat))
+void bn_backward_ws_layout(float* ws, int C, float** part, float** k2, float** k3);
+int bn_backward_finalize(const float* part, int chunks, int C, double rows, float* dgamma, float* dbeta, float* k2, float* k3, hipStream_t st);
 size_t bn_backward_ws_floats(int C);      // (includes the per-block |g| maxima of the f16x2 scale bound)
 // diagnostic: out[r*C + c] = 1 where relu_mask_bwd keeps the gradient (BN output > 0), else 0
 int relu_mask_export(const float* x, long long rows, int C, BnBuf bn, unsigned char* out, hipStream_t st);

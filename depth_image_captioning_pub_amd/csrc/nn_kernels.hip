@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
                                                                unsigned short* __restrict__ hi,
                                                                unsigned short* __restrict__ mid,
                                                                unsigned short* __restrict__ lo, unsigned* __restrict__ status,
-                                                               FastDiv dC4, FastDiv dPW, FastDiv dPH) {
+                                                               FastDiv dC4, FastDiv dPW, FastDiv dPH, float* __restrict__ xsel) {      // xsel (nullable): the RAW input value at each window's argmax
   const unsigned total = (unsigned)B * PH * PW * C4;       // < 2^31 (checked by the host)
   const unsigned stride = gridDim.x * 256u;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += stride) {
@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
       sh = *reinterpret_cast<const float4*>(bn.shift + c4 * 4);
     }
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 braw = make_float4(0.f, 0.f, 0.f, 0.f);
     uchar4 bi = make_uchar4(0, 0, 0, 0);
     for (int kh = 0; kh < k; ++kh) {
       const int h = ph * s - p + kh;
@@ -361,17 +362,19 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
         const int w = pw * s - p + kw;
         if ((unsigned)w >= (unsigned)W) continue;
         float4 v = reinterpret_cast<const float4*>(x)[(((long long)b * H + h) * W + w) * C4 + c4];
+        const float4 raw = v;
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const unsigned char id = (unsigned char)(kh * k + kw);
-        if (v.x > best.x) { best.x = v.x; bi.x = id; }
-        if (v.y > best.y) { best.y = v.y; bi.y = id; }
-        if (v.z > best.z) { best.z = v.z; bi.z = id; }
-        if (v.w > best.w) { best.w = v.w; bi.w = id; }
+        if (v.x > best.x) { best.x = v.x; bi.x = id; braw.x = raw.x; }
+        if (v.y > best.y) { best.y = v.y; bi.y = id; braw.y = raw.y; }
+        if (v.z > best.z) { best.z = v.z; bi.z = id; braw.z = raw.z; }
+        if (v.w > best.w) { best.w = v.w; bi.w = id; braw.w = raw.w; }
       }
     }
     if (y) reinterpret_cast<float4*>(y)[i] = best;
     if (idx) reinterpret_cast<uchar4*>(idx)[i] = bi;
+    if (xsel) reinterpret_cast<float4*>(xsel)[i] = braw;
     if (hi) {     // also (or only) as paired bf16x3 planes: the pooled map feeds a bf16x3 convolution (saves the split pass)
       const long long off = plane_offset((long long)row, c4 * 4, C4 / 8, 1);
       unsigned short h[4], m[4], l[4];
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(256) bn_relu_maxpool_kernel(const float* __res
 }
 
 int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn, int relu, int k, int s, int p,
-                    float* y, unsigned char* idx, hipStream_t st, unsigned short* const planes[3], unsigned* status) {
+                    float* y, unsigned char* idx, hipStream_t st, unsigned short* const planes[3], unsigned* status, float* xsel) {
   DIC_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
   DIC_REQUIRE(y || planes, "maxpool: no output");
   DIC_REQUIRE(!planes || C % 32 == 0, "maxpool: plane output needs C %% 32");
@@ -402,7 +405,7 @@ int bn_relu_maxpool(const float* x, int B, int H, int W, int C, const BnBuf* bn,
   BnBuf z{};
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, x, B, H, W, C / 4, bn ? *bn : z,
                      bn ? 1 : 0, relu, k, s, p, PH, PW, y, idx, planes ? planes[0] : nullptr, planes ? planes[1] : nullptr,
-                     planes ? planes[2] : nullptr, status, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)PW), make_fastdiv((unsigned)PH));
+                     planes ? planes[2] : nullptr, status, make_fastdiv((unsigned)(C / 4)), make_fastdiv((unsigned)PW), make_fastdiv((unsigned)PH), xsel);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }
@@ -808,6 +811,18 @@ int bn_backward(float* dy_dx, const float* x, long long rows, int C, const float
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, st, dy_dx, x, n4, C / 4, gamma, bn, k2, k3,
                      dx_planes ? dx_planes[0] : nullptr, dx_planes ? dx_planes[1] : nullptr,
                      dx_planes ? dx_planes[2] : nullptr, f16x2 ? (const float*)f16->slot : nullptr);
+  DIC_LAUNCH_CHECK();
+  return DIC_OK;
+}
+
+// pieces of bn_backward for callers that produce the partial sums themselves (depth_layer1.hip): the workspace layout and the finalize
+void bn_backward_ws_layout(float* ws, int C, float** part, float** k2, float** k3) {
+  *part = ws; *k2 = ws + (size_t)kBnChunksMax * 2 * C; *k3 = *k2 + C;
+}
+int bn_backward_finalize(const float* part, int chunks, int C, double rows, float* dgamma, float* dbeta, float* k2, float* k3, hipStream_t st) {
+  DIC_REQUIRE(chunks >= 1 && chunks <= kBnChunksMax && C % 64 == 0, "bn_backward_finalize: chunks <= %d, C %% 64", kBnChunksMax);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, part, chunks, C, rows, dgamma, dbeta, k2, k3,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (unsigned*)nullptr);
   DIC_LAUNCH_CHECK();
   return DIC_OK;
 }

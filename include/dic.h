@@ -441,6 +441,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
  *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
  *   116 117      depth encoder conv2 / conv3 (forward and both gradients): exact bf16x3 split / f16x2 with device-resident scales (default)
+ *   180 181      backward of the depth encoder's first layer: three passes over its full-size map and gradient / sparse form without either
+ *                (default; csrc/depth_layer1.hip)
  *   118 119      weight gradients whose output is 32..255 tiles of 128x128 (the depth encoder's two): 64x64 tiles with the caller's K
  *                split / persistent warp-specialised kernel with every tile cut into K slices (default)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /

@@ -280,6 +280,40 @@ def test_resnet_forward_with_bn_apply_folded_into_1x1_convs_matches_plane_route(
             assert torch.equal(y, y0) and torch.equal(st, s0), (code, dy, ds)
 
 
+@pytest.mark.parametrize("B,size", [(16, 224), (3, 130), (2, 520)])
+def test_depth_encoder_layer1_sparse_backward_equals_dense(lib, B, size):
+    """Round 4: the backward of the depth encoder's first layer without its full-size gradient (csrc/depth_layer1.hip, switch 181,
+    default) against the three dense passes it replaces (180) on the same tape: the gradients of conv1.weight, bn1.weight and bn1.bias
+    agree to 2e-5 of each tensor's scale (both evaluate the same sums; the sparse form keeps the long ones in fp64), every other
+    gradient is bit-identical (nothing upstream of layer 1 changed), and conv1.bias - whose true gradient in front of a train-mode
+    BatchNorm is exactly zero - is exactly zero instead of rounding noise.  Bench shape, a small odd map and a wide one."""
+    enc, st = syn.depth_encoder_weights(seed=124)
+    depth = syn.depth_maps(B, seed=123, size=size).to(DEV)
+    f, tape = native.depth_encoder_forward(_dev(enc), _dev(st), depth, train=True, compact=(size == 224))
+    g = torch.Generator().manual_seed(5)
+    dfeat = (torch.randn(f.shape, generator=g) * 1e-2).to(DEV)
+    out = {}
+    try:
+        for code in (180, 181):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            grads = native.depth_encoder_backward(tape, dfeat)
+            torch.cuda.synchronize()
+            out[code] = {k: v.clone() for k, v in grads.items()}
+    finally:
+        lib.dic_debug_force_staged_gemm(181)
+    for k in out[180]:
+        a, b = out[180][k], out[181][k]
+        assert torch.isfinite(b).all(), k
+        if k == "conv1.bias":
+            assert not bool(b.any()), "the sparse form writes the exactly-zero bias gradient as zero"
+        elif k in ("conv1.weight", "bn1.weight", "bn1.bias"):
+            d, sc = float((a - b).abs().max()), float(a.abs().max())
+            print(f"{k}: max |sparse - dense| / scale = {d / sc:.2e}")
+            assert d <= 2e-5 * sc, (k, d, sc)
+        else:
+            assert torch.equal(a, b), k
+
+
 def test_resnet_forward_with_bn_apply_inside_the_halo_kernel_matches_plane_route(lib):
     """Round 4: in the f16x2 format the 3x3 convolutions of 14x14 maps (35 of the 50 blocks) read the RAW output of conv1 and form
     relu(bn1(.)) in the LDS-halo kernel's producer waves (switch 109, default) instead of reading planes written by a bn_apply_planes
