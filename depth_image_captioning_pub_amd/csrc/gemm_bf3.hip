@@ -1511,12 +1511,12 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
           __builtin_amdgcn_s_barrier();
           halo_prev = false;
           if (tap == 0 && n + 1 < nchunks) {
-            if constexpr (BNA) issue_raw(n + 1); else if (!(ABL & 2)) issue_halo(n + 1);
-            halo_prev = BNA || !(ABL & 2);
+            if constexpr (BNA) { if (!(ABL & 2)) issue_raw(n + 1); } else if (!(ABL & 2)) issue_halo(n + 1);
+            halo_prev = !(ABL & 2);
           }
           if (!(ABL & 1) && g + NSTB < total) issue_b();
           // (BNA) the loads issued at tap 0 are older than weight tile g+3 of that tap, which the wait of tap 2 has seen land
-          if constexpr (BNA) if (tap == 2 && n + 1 < nchunks) transform_raw(n + 1);
+          if constexpr (BNA) if (!(ABL & 2) && tap == 2 && n + 1 < nchunks) transform_raw(n + 1);
         }
     return;
   }
@@ -1544,13 +1544,13 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
   u32x4 fa[2][2][3], fb[2][2][3];
   // A fragments of k-step KS_: pixel q = QB_[i] + 16*kh + kw of halo buffer HB_, 16-B slot (2*KS_ + h) ^ key(q)
 #define DIC_HALO_READ_A(KS_, HB_, QB_, TAPOFF_)                                                                      \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                    \
+  if constexpr (!(ABL & 8)) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                    \
     const unsigned q = (unsigned)((QB_)[i] + (TAPOFF_));                                                             \
     const unsigned a = sbase0 + (unsigned)((HB_) * HBUF * 2) + q * 64u + ((((unsigned)(2 * (KS_) + h)) ^ ((q >> 2) & 3u)) << 4); \
     _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) bf3_lds_read(fa[KS_][i][pl], a + (unsigned)(pl * HPLANE * 2)); \
   }
 #define DIC_HALO_READ_B(KS_, ST_)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
+  if constexpr (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
       bf3_lds_read(fb[KS_][j][pl], sbase0 + (unsigned)((2 * HBUF + (ST_) * BSTAGE + pl * BPLANE) * 2) + offB + (unsigned)(j * 32 * 64) + posB[KS_]);
 #define DIC_PIPE_PIN(KS_)                                                                                            \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                 \
@@ -1707,6 +1707,7 @@ static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (4
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_ablate = 0;           // 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 static int g_bf3_bn_ablate = 0;        // on-the-fly-operand kernel, timing only (wrong results): bit 0 = no residual read, bit 1 = no fp32 copy written (57..59)
+static int g_bf3_halo_bna_ablate = 0;  // LDS-halo kernel, on-the-fly form, timing only (wrong results): bit 0 = no weight DMA in the loop, bit 1 = no input loads / transform in the loop (64..66)
 #else
 constexpr int g_bf3_stages = 2, g_bf3_ws = 1, g_bf3_ablate = 0;
 #endif
@@ -1754,8 +1755,9 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
   if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
   if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
-  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; if (code == 50) g_bf3_bn_ablate = 0; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
+  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; if (code == 50) g_bf3_bn_ablate = g_bf3_halo_bna_ablate = 0; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
   if (code >= 57 && code <= 59) { g_bf3_bn_ablate = code - 56; return 0; }       // (50 clears it)
+  if (code >= 64 && code <= 69) { g_bf3_halo_bna_ablate = code <= 66 ? code - 63 : code == 67 ? 4 : code == 68 ? 12 : 8; return 0; }  // (50 clears it; 67 / 68 / 69: no B / no A and B / no A fragment reads)
   if (code == 77) { g_bf3_ws = 0; return 0; }
   if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
 #endif
@@ -1947,6 +1949,14 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
 #endif
     if (p.fmt == 1) {
       if (halo_bna && cg.W == 28) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9>), dim3(grid), dim3(512), 0, st, p);
+#ifdef DIC_EXPERIMENTS
+      else if (halo_bna && g_bf3_halo_bna_ablate == 1) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<1, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 2) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<2, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 3) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<3, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 4) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<4, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 8) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<8, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 12) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<12, 1, true>), dim3(grid), dim3(512), 0, st, p);
+#endif
       else if (halo_bna) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true>), dim3(grid), dim3(512), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8>), dim3(grid), dim3(768), 0, st, p);

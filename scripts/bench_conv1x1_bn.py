@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--fmt", type=int, default=0, help="operand format: 0 = bf16x3, 1 = f16x2")
 ap.add_argument("--switches", default="", help="comma-separated dic_debug_force_staged_gemm codes")
+ap.add_argument("--only", default="", help="run only the shapes whose name contains this")
 ap.add_argument("--rotate", type=int, default=1, help="cycle through this many input / output buffer sets (> 256 MiB in total: no launch finds its operands in the Infinity Cache)")
 a = ap.parse_args()
 lib = _lib.load()
@@ -57,6 +58,8 @@ B = a.batch
 for name, M, Cin, CO in (("layer2 conv1", B * 784, 512, 128), ("layer2 conv3", B * 784, 128, 512), ("layer3 conv1", B * 196, 1024, 256),
                          ("layer3 conv3", B * 196, 256, 1024), ("layer4 conv1", B * 49, 2048, 512), ("layer4 conv3", B * 49, 512, 2048),
                          ("layer1 conv3", B * 3136, 64, 256)):
+    if a.only not in name:
+        continue
     raws = [torch.randn(M, Cin, device=DEV) for _ in range(a.rotate)]
     ress = [torch.randn(M, Cin, device=DEV) for _ in range(a.rotate)]
     outs = [torch.empty(M, Cin, device=DEV) for _ in range(a.rotate)]
