@@ -281,6 +281,20 @@ template <int BR, int NPL> struct Bf3LoaderFor<OPK_ROWK, BR, NPL> { typedef Bf3B
 __device__ __forceinline__ void bf3_lds_read(u32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
+template <int OFF>
+__device__ __forceinline__ void bf3_lds_read_off(u32x4& dst, unsigned addr) {      // OFF: instruction offset, < 65536
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// planes of the p-th product of a k-step, in the order every kernel of this file adds them: bf16x3 (2,0) (0,2) (1,1) (1,0) (0,1) (0,0);
+// f16x2 (1,0) (0,1) (0,0)
+constexpr int bf3_prod_plane_a(int npl, int p) { return npl == 3 ? (p == 0 ? 2 : p == 2 || p == 3 ? 1 : 0) : (p == 0 ? 1 : 0); }
+constexpr int bf3_prod_plane_b(int npl, int p) { return npl == 3 ? (p == 1 ? 2 : p == 2 || p == 4 ? 1 : 0) : (p == 1 ? 1 : 0); }
+// f(std::integral_constant<int, I>) for I = 0 .. N-1, in order (an unrolled loop whose index is a constant expression)
+template <int I, int N, class F>
+__device__ __forceinline__ void bf3_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); bf3_static_for<I + 1, N>(f); }
+}
 typedef float f32x16_ __attribute__((ext_vector_type(16)));
 template <int FMT>
 __device__ __forceinline__ f32x16_ bf3_mfma(const u32x4& a, const u32x4& b, const f32x16_& c) {
@@ -500,7 +514,9 @@ __device__ __forceinline__ int few_tiles_remap(int b, int T, int sp, int G) {
 // vector instructions between "the slot's data has arrived" and "its LDS image is written", longer than the computing wave's 24 MFMAs
 // of the same K tile: the producer, not the matrix pipe, set the pace (1.34 us per K tile against 0.83 us for the plane kernel).  Eight
 // producer waves (two per SIMD beside the computing wave: 768 threads, <= 168 registers) halve that chain and overlap two of them per SIMD.
-template <int AK, int ABL = 0, int NST = 3, int FMT = 0, int NPW = 4, int DA_ = 4>      // DA_: input slots in flight per producer wave (on-the-fly operand); FMT: operand format (top of the file); ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
+// ILV (round 4, default): the computing waves issue one fragment read in the gap behind each matrix instruction instead of a block of reads
+// in front of each k-step's matrix instructions (see conv3x3_bf3_halo_kernel); same products in the same order, bit-identical to ILV = 0.
+template <int AK, int ABL = 0, int NST = 3, int FMT = 0, int NPW = 4, int DA_ = 4, int ILV = 1>      // DA_: input slots in flight per producer wave (on-the-fly operand); FMT: operand format (top of the file); ABL (measurement only): 1 = the producer waves issue nothing inside the loop, 3 = A always re-fetches K tile 0 of its output tile (cache-hot A), 4 = A and B both; NST: ring stages
 __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(const Bf3Params p) {
   constexpr int BM = 128, BN = 128;
   static_assert(NPW == 4 || (NPW == 8 && AK == OPK_ROWK_BN), "eight producer waves: on-the-fly operand only");
@@ -863,6 +879,46 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
     for (int kt = 0; kt < nkj; ++kt, ++g) {
       const int stn = st == NST - 1 ? 0 : st + 1;
       const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
+      if constexpr (ILV != 0 && ABL != 6) {
+        constexpr int NP = NPL == 3 ? 6 : 3;
+        // ---- k-step 0 (its fragments were requested during the previous slot's second half); k-step 1's fragments in the gaps
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DIC_PIPE_PIN(0)
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned a1 = sb + offA + pos[1], b1 = sb + (unsigned)(AOPER * 2) + offB + pos[1];
+        bf3_static_for<0, 4 * NP>([&](auto mc) {
+          constexpr int m = decltype(mc)::value, ai = (m & 3) >> 1, aj = m & 1;
+          acc[ai][aj] = bf3_mfma<FMT>(fa[0][ai][bf3_prod_plane_a(NPL, m >> 2)], fb[0][aj][bf3_prod_plane_b(NPL, m >> 2)], acc[ai][aj]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (m < 2 * NPL) {
+            bf3_lds_read_off<(m % NPL) * APLANE * 2 + (m / NPL) * 32 * 64>(fa[1][m / NPL][m % NPL], a1);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (m < 4 * NPL) {
+            bf3_lds_read_off<(m % NPL) * BPLANE * 2 + ((m - 2 * NPL) / NPL) * 32 * 64>(fb[1][(m - 2 * NPL) / NPL][m % NPL], b1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this stage is in registers
+        DIC_PIPE_PIN(1)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- k-step 1; k-step 0 of the next slot in the gaps (past the last slot: a harmless re-read of a ring stage)
+        const unsigned a0 = sbn + offA + pos[0], b0 = sbn + (unsigned)(AOPER * 2) + offB + pos[0];
+        bf3_static_for<0, 4 * NP>([&](auto mc) {
+          constexpr int m = decltype(mc)::value, ai = (m & 3) >> 1, aj = m & 1;
+          acc[ai][aj] = bf3_mfma<FMT>(fa[1][ai][bf3_prod_plane_a(NPL, m >> 2)], fb[1][aj][bf3_prod_plane_b(NPL, m >> 2)], acc[ai][aj]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (m < 2 * NPL) {
+            bf3_lds_read_off<(m % NPL) * APLANE * 2 + (m / NPL) * 32 * 64>(fa[0][m / NPL][m % NPL], a0);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (m < 4 * NPL) {
+            bf3_lds_read_off<(m % NPL) * BPLANE * 2 + ((m - 2 * NPL) / NPL) * 32 * 64>(fb[0][(m - 2 * NPL) / NPL][m % NPL], b0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        st = stn;
+        continue;
+      }
       DIC_PIPE_READ_A(1, sb, 0) DIC_PIPE_READ_A(1, sb, 1) DIC_PIPE_READ_B(1, sb, 0) DIC_PIPE_READ_B(1, sb, 1)
       if constexpr (NPL == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
       DIC_PIPE_PIN(0)
@@ -1299,7 +1355,12 @@ constexpr int kHaloBnTab = 512;       // channels of the on-the-fly operand of t
 //   * HROW / RMAX: padded pixels per halo row and halo rows of a tile - 16 / 13 for 14x14 maps; 32 / 9 for 28x28 maps (ResNet layer 2;
 //     BNA form only: its halo buffers hold the two f16x2 planes, 2 x 36 KB, where three planes of that size would not fit).  RMAX is the
 //     largest number of padded rows any 128-pixel tile touches (brute force over every tile start: 13 | 9).
-template <int ABL, int FMT = 0, bool BNA = false, int HROW = 16, int RMAX = 13>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
+//   * ILV (round 4): the computing waves issue ONE fragment read (and its address arithmetic) in the gap behind each matrix instruction
+//     instead of eight reads in a row in front of twelve matrix instructions: a wave issues in order, so a block of reads + ~20 address
+//     instructions in front of the first MFMA of a k-step is ~150 cycles during which the matrix pipe of its SIMD (one computing wave per
+//     SIMD) has nothing to do, while one ds_read_b128 + 2-3 vector instructions fit the 32-cycle shadow of an MFMA.  Same products, same
+//     order per accumulator: bit-identical to ILV = 0.
+template <int ABL, int FMT = 0, bool BNA = false, int HROW = 16, int RMAX = 13, int ILV = 0>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
 __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p) {
   static_assert(!BNA || FMT == 1, "on-the-fly halo operand: f16x2 only");
   static_assert((HROW == 16 && RMAX == 13) || (BNA && HROW == 32 && RMAX == 9), "halo geometry: 14x14 maps, or 28x28 with the on-the-fly operand");
@@ -1563,7 +1624,26 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
   { int tm, tn; tile_of(0, tm, tn); qb[0] = pixel_base(tm, 0); qb[1] = pixel_base(tm, 1); }
   qbn[0] = qb[0]; qbn[1] = qb[1];
   __builtin_amdgcn_s_barrier();                    // halo chunk 0 and weight tile 0 are in LDS
-  DIC_HALO_READ_A(0, 0, qb, 0) DIC_HALO_READ_B(0, 0)
+  // ---- ILV form: addresses kept in registers.  A fragment of k-step 0: aaddr[i] (plane pl at +pl*HPLANE*2 as an instruction offset);
+  // k-step 1 = the same address with bit 5 flipped ((2 + h) ^ key = (h ^ key) ^ 2); B fragments: stage base + bl[k-step]
+  unsigned aaddr[2] = {0u, 0u};
+  const unsigned bl[2] = {offB + posB[0], offB + posB[1]};
+  auto a_addr0 = [&](int hbuf, int q) {
+    return sbase0 + (unsigned)(hbuf * HBUF * 2) + (unsigned)q * 64u + ((((unsigned)h) ^ (((unsigned)q >> 2) & 3u)) << 4);
+  };
+  if constexpr (ILV == 0) {
+    DIC_HALO_READ_A(0, 0, qb, 0) DIC_HALO_READ_B(0, 0)
+  } else {
+    aaddr[0] = a_addr0(0, qb[0]); aaddr[1] = a_addr0(0, qb[1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) bf3_lds_read(fa[0][i][pl], aaddr[i] + (unsigned)(pl * HPLANE * 2));
+    DIC_HALO_READ_B(0, 0)
+  }
+  // MFMA m of a k-step: product m / 4 of the format's list, accumulator ((m % 4) / 2, m % 2); read r of a k-step: r < 2 NPL = A fragment
+  // (tile r / NPL, plane r % NPL), else B fragment
+  constexpr int NP = NPL == 3 ? 6 : 3;
 
   int g = 0, st = 0, n = 0;                        // slot, its weight stage, its (global) chunk
   for (int j = 0; j < nwork; ++j) {
@@ -1574,6 +1654,59 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       for (int tap = 0; tap < 9; ++tap, ++g) {
         const int stn = st == NSTB - 1 ? 0 : st + 1;
         const int kh = tap >= 6 ? 2 : tap >= 3 ? 1 : 0, kw = tap - 3 * kh, tapoff = kh * HROW + kw;
+        if constexpr (ILV != 0) {
+          // ---- k-step 0 (fragments requested during the previous slot's second half); k-step 1's fragments in the gaps
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          DIC_PIPE_PIN(0)
+          __builtin_amdgcn_sched_barrier(0);
+          // (the next slot - next tap / next chunk = other buffer / next tile; past the last slot: a harmless re-read - is chosen here and its
+          //  A addresses are formed in two of this k-step's read-free gaps)
+          const int t1 = tap + 1, kh1 = t1 >= 6 ? 2 : t1 >= 3 ? 1 : 0;
+          const bool same_chunk = tap < 8, next_tile = !same_chunk && cc + 1 >= ncj;
+          const int nhb = same_chunk ? hb : hb ^ 1, noff = same_chunk ? kh1 * HROW + (t1 - 3 * kh1) : 0;
+          unsigned baddr = 0u, an[2] = {0u, 0u};
+          bf3_static_for<0, 4 * NP>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, ai = (m & 3) >> 1, aj = m & 1;
+            acc[ai][aj] = bf3_mfma<FMT>(fa[0][ai][bf3_prod_plane_a(NPL, m >> 2)], fb[0][aj][bf3_prod_plane_b(NPL, m >> 2)], acc[ai][aj]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m < 2 * NPL) {
+              if constexpr (!(ABL & 8)) bf3_lds_read_off<(m % NPL) * HPLANE * 2>(fa[1][m / NPL][m % NPL], aaddr[m / NPL] ^ 32u);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (m < 4 * NPL) {
+              if constexpr (m == 2 * NPL) baddr = sbase0 + (unsigned)((2 * HBUF + st * BSTAGE) * 2) + bl[1];
+              if constexpr (!(ABL & 4)) bf3_lds_read_off<(m % NPL) * BPLANE * 2 + ((m - 2 * NPL) / NPL) * 32 * 64>(fb[1][(m - 2 * NPL) / NPL][m % NPL], baddr);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (m < 4 * NPL + 2) {
+              an[m - 4 * NPL] = a_addr0(nhb, (next_tile ? qbn[m - 4 * NPL] : qb[m - 4 * NPL]) + noff);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+          aaddr[0] = an[0]; aaddr[1] = an[1];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          DIC_PIPE_PIN(1)
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- k-step 1; k-step 0 of the NEXT slot in the gaps
+          bf3_static_for<0, 4 * NP>([&](auto mc) {
+            constexpr int m = decltype(mc)::value, ai = (m & 3) >> 1, aj = m & 1;
+            acc[ai][aj] = bf3_mfma<FMT>(fa[1][ai][bf3_prod_plane_a(NPL, m >> 2)], fb[1][aj][bf3_prod_plane_b(NPL, m >> 2)], acc[ai][aj]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m < 2 * NPL) {
+              if constexpr (!(ABL & 8)) bf3_lds_read_off<(m % NPL) * HPLANE * 2>(fa[0][m / NPL][m % NPL], aaddr[m / NPL]);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (m < 4 * NPL) {
+              if constexpr (m == 2 * NPL) baddr = sbase0 + (unsigned)((2 * HBUF + stn * BSTAGE) * 2) + bl[0];
+              if constexpr (!(ABL & 4)) bf3_lds_read_off<(m % NPL) * BPLANE * 2 + ((m - 2 * NPL) / NPL) * 32 * 64>(fb[0][(m - 2 * NPL) / NPL][m % NPL], baddr);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+          if (tap == 1 && cc == ncj - 1 && j + 1 < nwork) {     // next tile's pixel bases, well before its first fragment reads
+            int tm, tn; tile_of(j + 1, tm, tn);
+            qbn[0] = pixel_base(tm, 0); qbn[1] = pixel_base(tm, 1);
+          }
+          st = stn;
+          continue;
+        }
         DIC_HALO_READ_A(1, hb, qb, tapoff) DIC_HALO_READ_B(1, st)
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 * NPL) : "memory");
         DIC_PIPE_PIN(0)
@@ -1687,6 +1820,7 @@ static int g_bf3_force = 0;            // 11 / 21 force the 64x64 / 128x64 workg
 static int g_bf3_persist_grid = 224;   // persistent kernels: at most this many workgroups (one per CU).  224 rather than 256: same time per launch
                                        // (operand delivery, not CU count, bounds them) and the main stream's short kernels find free CUs: pipelined step
                                        // 14.28 -> 14.02 ms
+static int g_bf3_halo_ilv = 1;         // codes 120 / 121: computing waves of the f16x2 128x128 kernels (LDS-halo on-the-fly form, persistent 1x1 / gathered) read their fragments in a block / one per MFMA gap (default)
 static int g_bf3_halo = 1;             // 3x3 convolutions of 14x14 maps on the LDS-halo kernel: 0 = off (code 75), 1 = from 128 tiles (78, default), 2 = always (74)
 static int g_bf3_persist_policy = 4;   // codes 70..73, 79: 0 = never, 1 = only K <= 64, 2 = also K <= 256 on >= 3072-tile grids, 3 = 1x1 convolutions by CU fill, 4 = also the gathered (im2col) ones
 static int g_bf3_tail_mode = 0;        // codes 60..63: 1 = no remainder-tile K split, 2 = split also for T >= 7*256, 3 = split by 4 at most
@@ -1747,6 +1881,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 92 || code == 93) { g_bf3_few_remap = code - 92; return 0; }                  // few-tiles launches (every tile in K slices): plain order / slice z on XCD z (default)
   if (code == 94 || code == 95) { g_bf3_halo28 = code - 94; return 0; }                      // LDS-halo kernel for 28x28 maps (on-the-fly operand form): never / by policy (default)
   if (code == 96 || code == 97) { g_bf3_narrow_bn = code - 96; return 0; }                   // on-the-fly-operand 1x1 kernel for CO = 64 (layer 1's conv1): never / by policy (default)
+  if (code == 120 || code == 121) { g_bf3_halo_ilv = code - 120; return 0; }               // LDS-halo kernel, on-the-fly form: fragment reads in a block / interleaved with the MFMAs (default)
   if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)
 #ifdef DIC_EXPERIMENTS
   if (code == 106 || code == 107) { g_bf3_ws256_bn = code - 106; return 0; }        // parked: conv3-style on-the-fly operand (no residual, no copy) on the 256x128 kernel: never (default) / by policy
@@ -1948,7 +2083,8 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (p.a_raw && (g_bf3_bn_ablate & 2)) p.a_out = nullptr;
 #endif
     if (p.fmt == 1) {
-      if (halo_bna && cg.W == 28) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9>), dim3(grid), dim3(512), 0, st, p);
+      if (halo_bna && cg.W == 28 && g_bf3_halo_ilv) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && cg.W == 28) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9>), dim3(grid), dim3(512), 0, st, p);
 #ifdef DIC_EXPERIMENTS
       else if (halo_bna && g_bf3_halo_bna_ablate == 1) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<1, 1, true>), dim3(grid), dim3(512), 0, st, p);
       else if (halo_bna && g_bf3_halo_bna_ablate == 2) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<2, 1, true>), dim3(grid), dim3(512), 0, st, p);
@@ -1957,12 +2093,16 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       else if (halo_bna && g_bf3_halo_bna_ablate == 8) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<8, 1, true>), dim3(grid), dim3(512), 0, st, p);
       else if (halo_bna && g_bf3_halo_bna_ablate == 12) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<12, 1, true>), dim3(grid), dim3(512), 0, st, p);
 #endif
+      else if (halo_bna && g_bf3_halo_ilv) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo_bna) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true>), dim3(grid), dim3(512), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8 && g_bf3_slots == 6) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 6>), dim3(grid), dim3(768), 0, st, p);
+      else if (p.a_raw && g_bf3_producers == 8 && !g_bf3_halo_ilv) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8, 4, 0>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw && g_bf3_producers == 8) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1, 8>), dim3(grid), dim3(768), 0, st, p);
       else if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (im && !g_bf3_halo_ilv) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL, 0, 3, 1, 4, 4, 0>), dim3(grid), dim3(512), 0, st, p);
       else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_IM2COL, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (!g_bf3_halo_ilv) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 3, 1, 4, 4, 0>), dim3(grid), dim3(512), 0, st, p);
       else hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK, 0, 3, 1>), dim3(grid), dim3(512), 0, st, p);
     } else
     if (p.a_raw) hipLaunchKernelGGL((gemm_bf3_persist_ws_kernel<OPK_ROWK_BN>), dim3(grid), dim3(512), 0, st, p);

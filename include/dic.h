@@ -443,6 +443,9 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   116 117      depth encoder conv2 / conv3 (forward and both gradients): exact bf16x3 split / f16x2 with device-resident scales (default)
  *   180 181      backward of the depth encoder's first layer: three passes over its full-size map and gradient / sparse form without either
  *                (default; csrc/depth_layer1.hip)
+ *   120 121      mode 2: computing waves of the 128x128 kernels (LDS-halo 3x3 in its on-the-fly form, persistent 1x1 / gathered) read their
+ *                fragments in a block in front of each k-step's matrix instructions / one read in the gap behind each matrix
+ *                instruction (default); bit-identical
  *   118 119      weight gradients whose output is 32..255 tiles of 128x128 (the depth encoder's two): 64x64 tiles with the caller's K
  *                split / persistent warp-specialised kernel with every tile cut into K slices (default)
  * Unknown codes are rejected (DIC_ERR_ARG).  Ablation switches and the parked kernels (deep-pipelined / computing-wave-DMA /

@@ -371,6 +371,27 @@ def test_resnet_forward_downsample_bn_inside_the_1x1_kernel_is_bit_identical(lib
     assert torch.equal(out[98][0], out[99][0]) and torch.equal(out[98][1], out[99][1])
 
 
+def test_resnet_forward_with_interleaved_fragment_reads_is_bit_identical(lib):
+    """Round 4 (f16x2): the computing waves of the 128x128 kernels (LDS-halo 3x3, on-the-fly 1x1, gathered, row-major) issue one
+    fragment read in the gap behind each matrix instruction (switch 121, default) instead of a block of reads in front of each k-step's
+    matrix instructions (120).  Same products in the same order per accumulator: features and running statistics agree bit for bit."""
+    w = syn.resnet152_weights(seed=126)
+    imgs = syn.rgb_images(64, seed=124).to(DEV)
+    out = {}
+    try:
+        for code in (120, 121):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            wd = _dev(w)
+            runner = native.ResNetRunner(wd, conv_mode="f16x2")
+            y = runner.forward(imgs, train_bn=True, compact=True)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and int(runner.status_word().item()) == 0
+            out[code] = (y.clone(), torch.cat([wd[k].flatten() for k in sorted(wd) if "running" in k]).clone())
+    finally:
+        lib.dic_debug_force_staged_gemm(121)
+    assert torch.equal(out[120][0], out[121][0]) and torch.equal(out[120][1], out[121][1])
+
+
 def test_layer1_kernels_reproducible_next_to_lds_heavy_kernels(lib):
     """The packed-FMA layer-1 kernels of the depth encoder (csrc/conv1_depth.hip), called alone through the library, repeated
     on identical inputs while a bf16x3 ResNet forward on its round-1 gather kernels (debug codes 70 75: three LDS-heavy

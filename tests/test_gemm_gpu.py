@@ -610,6 +610,19 @@ def test_conv3x3_halo_kernel_with_on_the_fly_operand(lib, B, Cin, CO, H):
             ys.append(y)
         assert torch.isfinite(ys[0]).all() and int(status.item()) == 0
         assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2]), "repeated launches differ"
+        # switch 120: the computing waves read their fragments in a block in front of each k-step's MFMAs (the form until round 4);
+        # 121 (default): one read per MFMA gap.  Same products in the same order: outputs and BatchNorm partials bit for bit
+        part_ilv = part.clone()
+        try:
+            assert lib.dic_debug_force_staged_gemm(120) == 0
+            y_blk = torch.full((M, CO), float("nan"), device=DEV)
+            part_blk = torch.zeros_like(part)
+            rc = lib.dic_debug_conv3x3_bn(ptr(raw), ptr(scale), ptr(shift), 1, B, H, H, Cin, pl(wp), CO, ptr(y_blk), ptr(part_blk), C.byref(mt), ptr(tail),
+                                          1024, out_scale, ptr(status), stream_ptr())
+            torch.cuda.synchronize()
+            assert rc == 0 and torch.equal(y_blk, ys[0]) and torch.equal(part_blk, part_ilv), "interleaved fragment reads changed the result"
+        finally:
+            lib.dic_debug_force_staged_gemm(121)
         ndiff = int((ys[0] != y_pl).sum())          # (a double-rounded activation element would show in its 9 * CO outputs, at rounding level)
         print(f"\noutputs that differ from the plane route: {ndiff} of {M * CO}")
         if H == 14:
