@@ -1038,8 +1038,11 @@ __global__ void __launch_bounds__(256 + 64 * NPW) gemm_bf3_persist_ws_kernel(con
 // on-the-fly form of gemm_bf3_persist_ws_kernel (iteration g: L(g+1), D(g+1) done -> transform slot g+1 -> barrier g -> D(g+3),
 // L(g+4)); the weight tiles stream by LDS-DMA as before.
 constexpr int kWs256BnTab = 512;      // channels of the on-the-fly operand of the 256x128 kernel (scale | shift table in LDS)
-template <int AK, int FMT = 0, bool BNA = false>
+// ILV (round 4; f16x2 only, where a second set of B fragment registers fits the 168-register budget): one fragment read in the gap behind
+// each matrix instruction, both operands double-buffered by k-step (see conv3x3_bf3_halo_kernel); bit-identical to ILV = 0.
+template <int AK, int FMT = 0, bool BNA = false, int ABL = 0, int ILV = 0>      // ABL (measurement only, wrong results): 1 = no DMA in the loop, 2 = no tile stores, 4 = no fragment reads
 __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Params p) {
+  static_assert(ILV == 0 || FMT == 1, "interleaved fragment reads of the 256x128 kernel: f16x2 only");
   static_assert(!BNA || (FMT == 1 && AK == OPK_ROWK), "on-the-fly operand of the 256x128 kernel: f16x2, row-major");
   constexpr int BM = 256, BN = 128;
   constexpr int NPL = Bf3Fmt<FMT>::NPL;
@@ -1217,7 +1220,7 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
       if (NST >= 3 && g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                // ... and the consumers are done with stage st
-      if (g + NST < total) prefetch(smem + st * STAGE);
+      if (!(ABL & 1) && g + NST < total) prefetch(smem + st * STAGE);
       st = st == NST - 1 ? 0 : st + 1;
     }
     return;
@@ -1238,10 +1241,10 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
   const unsigned sbase0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem;
   u32x4 fa[2][2][3], fb[2][3];                     // A: [k-step buffer][tile][plane];  B: [tile][plane]
 #define DIC_W_READ_A(KS_, SB_)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
+  if constexpr (!(ABL & 4)) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
       bf3_lds_read(fa[KS_][i][pl], (SB_) + (unsigned)(pl * APLANE * 2) + offA + (unsigned)(i * 32 * 64) + pos[KS_]);
 #define DIC_W_READ_B(KS_, SB_)                                                                                       \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
+  if constexpr (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                   \
       bf3_lds_read(fb[j][pl], (SB_) + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)(j * 32 * 64) + pos[KS_]);
 #define DIC_W_PIN(KS_)                                                                                               \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                 \
@@ -1253,13 +1256,66 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
   if constexpr (NPL == 3) { DIC_W_MFMA(KS_, 2, 0) DIC_W_MFMA(KS_, 0, 2) DIC_W_MFMA(KS_, 1, 1) }                     \
   DIC_W_MFMA(KS_, 1, 0) DIC_W_MFMA(KS_, 0, 1) DIC_W_MFMA(KS_, 0, 0)
   __builtin_amdgcn_s_barrier();                                    // slot 0 is in LDS
-  DIC_W_READ_A(0, sbase0)
+  u32x4 ga[2][2][ILV ? 2 : 1], gb[2][2][ILV ? 2 : 1];              // ILV form: [k-step buffer][tile][plane] for both operands
+  if constexpr (ILV != 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        bf3_lds_read(ga[0][i][pl], sbase0 + (unsigned)(pl * APLANE * 2) + offA + (unsigned)(i * 32 * 64) + pos[0]);
+        bf3_lds_read(gb[0][i][pl], sbase0 + (unsigned)(AOPER * 2 + pl * BPLANE * 2) + offB + (unsigned)(i * 32 * 64) + pos[0]);
+      }
+  } else {
+    DIC_W_READ_A(0, sbase0)
+  }
   int g = 0, st = 0;
   for (int j = 0; j < ntl; ++j) {
     for (int kt = 0; kt < nkt; ++kt, ++g) {
       const int stn = st == NST - 1 ? 0 : st + 1;
       const unsigned sb = sbase0 + (unsigned)(st * STAGE) * 2u, sbn = sbase0 + (unsigned)(stn * STAGE) * 2u;
       st = stn;
+      if constexpr (ILV != 0) {
+#define DIC_W_PIN2(KS_)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                   \
+    asm volatile("" : "+v"(ga[KS_][i][pl])); asm volatile("" : "+v"(gb[KS_][i][pl])); }
+        // ---- k-step 0 (fragments requested during the previous slot's second half); k-step 1's fragments in the gaps
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DIC_W_PIN2(0)
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned a1 = sb + offA + pos[1], b1 = sb + (unsigned)(AOPER * 2) + offB + pos[1];
+        bf3_static_for<0, 12>([&](auto mc) {
+          constexpr int m = decltype(mc)::value, ai = (m & 3) >> 1, aj = m & 1;
+          acc[ai][aj] = bf3_mfma<FMT>(ga[0][ai][bf3_prod_plane_a(2, m >> 2)], gb[0][aj][bf3_prod_plane_b(2, m >> 2)], acc[ai][aj]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (m < 4) {
+            if constexpr (!(ABL & 4)) bf3_lds_read_off<(m % 2) * APLANE * 2 + (m / 2) * 32 * 64>(ga[1][m / 2][m % 2], a1);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (m < 8) {
+            if constexpr (!(ABL & 4)) bf3_lds_read_off<(m % 2) * BPLANE * 2 + ((m - 4) / 2) * 32 * 64>(gb[1][(m - 4) / 2][m % 2], b1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DIC_W_PIN2(1)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- k-step 1; k-step 0 of the next slot in the gaps (past the last slot: a harmless re-read of a ring stage)
+        const unsigned a0 = sbn + offA + pos[0], b0 = sbn + (unsigned)(AOPER * 2) + offB + pos[0];
+        bf3_static_for<0, 12>([&](auto mc) {
+          constexpr int m = decltype(mc)::value, ai = (m & 3) >> 1, aj = m & 1;
+          acc[ai][aj] = bf3_mfma<FMT>(ga[1][ai][bf3_prod_plane_a(2, m >> 2)], gb[1][aj][bf3_prod_plane_b(2, m >> 2)], acc[ai][aj]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (m < 4) {
+            if constexpr (!(ABL & 4)) bf3_lds_read_off<(m % 2) * APLANE * 2 + (m / 2) * 32 * 64>(ga[0][m / 2][m % 2], a0);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (m < 8) {
+            if constexpr (!(ABL & 4)) bf3_lds_read_off<(m % 2) * BPLANE * 2 + ((m - 4) / 2) * 32 * 64>(gb[0][(m - 4) / 2][m % 2], b0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+#undef DIC_W_PIN2
+        continue;
+      }
       // k-step 0: its A fragments were requested one k-step ago; request its B fragments and k-step 1's A fragments
       DIC_W_READ_B(0, sb) DIC_W_READ_A(1, sb)
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * NPL) : "memory");
@@ -1296,6 +1352,9 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float* col = p.ep.C + (long long)(m0 + i * 32) * p.ep.ldc + n0 + jj * 32;
+        if constexpr ((ABL & 2) != 0) {
+          if (acc[i][jj][0] == 1.2345e-30f) col[0] = 0.f;      // (keeps the accumulators alive)
+        } else
         if (full) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) col[(long long)((r & 3) + 8 * (r >> 2)) * p.ep.ldc] = acc[i][jj][r];
@@ -1841,6 +1900,7 @@ static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (4
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
 static int g_bf3_ablate = 0;           // 1 = no DMA in the loop, 2 = also no LDS fragment reads (64x64 rowk only)
 static int g_bf3_bn_ablate = 0;        // on-the-fly-operand kernel, timing only (wrong results): bit 0 = no residual read, bit 1 = no fp32 copy written (57..59)
+static int g_bf3_ws256_ablate = 0;     // 256x128 kernel (f16x2, planes), timing only: 1 = no DMA in the loop, 2 = no tile stores, 3 = neither, 4 = no fragment reads (44..47)
 static int g_bf3_halo_bna_ablate = 0;  // LDS-halo kernel, on-the-fly form, timing only (wrong results): bit 0 = no weight DMA in the loop, bit 1 = no input loads / transform in the loop (64..66)
 #else
 constexpr int g_bf3_stages = 2, g_bf3_ws = 1, g_bf3_ablate = 0;
@@ -1890,8 +1950,9 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code >= 60 && code <= 63) { g_bf3_tail_mode = code - 60; return 0; }
   if (code >= 82 && code <= 89) { g_bf3_persist_grid = 256 - 16 * (code - 82); return 0; }      // persistent grids of at most 256, 240, ... 144 workgroups
   if (code == 42 || code == 43) { g_bf3_stages = code - 40; return 0; }
-  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; if (code == 50) g_bf3_bn_ablate = g_bf3_halo_bna_ablate = 0; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
+  if (code >= 50 && code <= 56) { g_bf3_ablate = code - 50; if (code == 50) g_bf3_bn_ablate = g_bf3_halo_bna_ablate = g_bf3_ws256_ablate = 0; return 0; }      // (54 / 55: persistent kernel with cache-hot A / A and B)
   if (code >= 57 && code <= 59) { g_bf3_bn_ablate = code - 56; return 0; }       // (50 clears it)
+  if (code >= 44 && code <= 47) { g_bf3_ws256_ablate = code - 43; return 0; }       // (50 clears it)
   if (code >= 64 && code <= 69) { g_bf3_halo_bna_ablate = code <= 66 ? code - 63 : code == 67 ? 4 : code == 68 ? 12 : 8; return 0; }  // (50 clears it; 67 / 68 / 69: no B / no A and B / no A fragment reads)
   if (code == 77) { g_bf3_ws = 0; return 0; }
   if (code == 22 || code == 23 || code == 26) { g_bf3_force = code; return 0; }
@@ -2119,7 +2180,15 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (ws256_bna) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, true>), dim3(grid), dim3(768), 0, st, p);
     else
 #endif
-    if (p.fmt == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1>), dim3(grid), dim3(768), 0, st, p);
+#ifdef DIC_EXPERIMENTS
+    if (p.fmt == 1 && !im && g_bf3_ws256_ablate == 1) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, false, 1>), dim3(grid), dim3(768), 0, st, p);
+    else if (p.fmt == 1 && !im && g_bf3_ws256_ablate == 2) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, false, 2>), dim3(grid), dim3(768), 0, st, p);
+    else if (p.fmt == 1 && !im && g_bf3_ws256_ablate == 3) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, false, 3>), dim3(grid), dim3(768), 0, st, p);
+    else if (p.fmt == 1 && !im && g_bf3_ws256_ablate == 4) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, false, 4>), dim3(grid), dim3(768), 0, st, p);
+    else
+#endif
+    if (p.fmt == 1 && !im && g_bf3_halo_ilv) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1, false, 0, 1>), dim3(grid), dim3(768), 0, st, p);
+    else if (p.fmt == 1 && !im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK, 1>), dim3(grid), dim3(768), 0, st, p);
 #ifdef DIC_EXPERIMENTS
     else if (im) hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_IM2COL>), dim3(grid), dim3(768), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf3_persist_ws256_kernel<OPK_ROWK>), dim3(grid), dim3(768), 0, st, p);

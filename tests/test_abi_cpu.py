@@ -128,4 +128,6 @@ def test_product_library_holds_no_parked_or_probe_code():
     # the 256x128 twelve-wave kernel left the parked set in round 3 - in one instantiation: row-major operands, f16x2 format
     ws256 = sorted({w for w in out.split() if "ws256" in w})
     # (the product holds exactly the plain f16x2 row-major instantiation; the on-the-fly-operand form of round 4 is parked)
-    assert ws256 and all(w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1ELb0EEEvNS_9Bf3ParamsE") for w in ws256), ws256
+    # (two forms of its computing waves' loop: fragment reads in a block / interleaved, switches 120 / 121; no ablation, no other operand kind)
+    assert ws256 and all(w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1ELb0ELi0ELi0EEEvNS_9Bf3ParamsE") or
+                         w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1ELb0ELi0ELi1EEEvNS_9Bf3ParamsE") for w in ws256), ws256
