@@ -1411,6 +1411,11 @@ __global__ void __launch_bounds__(768) gemm_bf3_persist_ws256_kernel(const Bf3Pa
 //     for the weight tiles issued after them cover them), transforms and writes the two plane images at tap 2, six K tiles before
 //     the computing waves first read them.  Padding pixels are written as zeros (the padding applies to the activation).
 constexpr int kHaloBnTab = 512;       // channels of the on-the-fly operand of the halo kernel (scale | shift table in LDS)
+//     58 / 7 for 56x56 maps (ResNet layer 1, 64 -> 64 channels: 2 x 52 KB of halo images + 48 KB of weight ring; its 64 output channels
+//     take the left half of the 128-column tile - weight rows 64..127 are out of the buffer's range and load as zeros, the epilogue's
+//     column guard drops them).  PARKED (experiments build, switch 127): correct (scripts/experiments/test_parked_kernels_gpu.py) and
+//     no faster - 110 us per launch against 17 + 85 us for the planes pass + gathered kernel it replaces (seven tiles of two chunks per
+//     workgroup: a 13-slot transform, a tile seam and a halo set-up per 18 K tiles), pipelined step 8.61 ms with it, 8.59 without;
 //   * HROW / RMAX: padded pixels per halo row and halo rows of a tile - 16 / 13 for 14x14 maps; 32 / 9 for 28x28 maps (ResNet layer 2;
 //     BNA form only: its halo buffers hold the two f16x2 planes, 2 x 36 KB, where three planes of that size would not fit).  RMAX is the
 //     largest number of padded rows any 128-pixel tile touches (brute force over every tile start: 13 | 9).
@@ -1422,10 +1427,11 @@ constexpr int kHaloBnTab = 512;       // channels of the on-the-fly operand of t
 template <int ABL, int FMT = 0, bool BNA = false, int HROW = 16, int RMAX = 13, int ILV = 0>      // FMT: operand format; ABL (measurement only): 1 = no weight DMA in the loop, 2 = no halo DMA in the loop, 3 = neither
 __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p) {
   static_assert(!BNA || FMT == 1, "on-the-fly halo operand: f16x2 only");
-  static_assert((HROW == 16 && RMAX == 13) || (BNA && HROW == 32 && RMAX == 9), "halo geometry: 14x14 maps, or 28x28 with the on-the-fly operand");
+  static_assert((HROW == 16 && RMAX == 13) || (BNA && HROW == 32 && RMAX == 9) || (BNA && HROW == 58 && RMAX == 7),
+                "halo geometry: 14x14 maps, or 28x28 / 56x56 with the on-the-fly operand");
   constexpr int BM = 128, BN = 128, NSTB = 3;
   constexpr int HPLANE = RMAX * HROW * BK3, HBUF = (BNA ? Bf3Fmt<FMT>::NPL : 3) * HPLANE;        // elements: 13 KB per plane, 39 KB per buffer (14x14)
-  constexpr int BPLANE = BN * BK3, BSTAGE = 3 * BPLANE;               // 24 KB per weight tile
+  constexpr int BPLANE = BN * BK3, BSTAGE = (BNA ? Bf3Fmt<FMT>::NPL : 3) * BPLANE;               // 24 KB per weight tile (16 KB in the on-the-fly form: two planes)
   constexpr int NPL = Bf3Fmt<FMT>::NPL;                               // planes in use (buffers keep three plane slots)
   constexpr int NHALO = (RMAX * NPL + 3) / 4;                          // halo DMA instructions per producer wave and chunk (10 | 7)
   constexpr int NB = 2 * NPL;                                          // weight DMA instructions per producer wave and K tile
@@ -1528,11 +1534,14 @@ __global__ void __launch_bounds__(512) conv3x3_bf3_halo_kernel(const Bf3Params p
       int tm, tn;
       tile_of(j, tm, tn);
       const int pr_lo = row_lo(tm);
+      // (one division per tile, wave-uniform; a slot's padded row pr_lo + r, r < RMAX <= H + 1, crosses at most one image boundary)
+      const int b_lo = __builtin_amdgcn_readfirstlane(pr_lo / (H + 1)), rr_lo = __builtin_amdgcn_readfirstlane(pr_lo - b_lo * (H + 1));
       rok = 0u;
 #pragma unroll
       for (int i = 0; i < NRAW; ++i) {
-        const int q = ps + 32 * i, r = q / HROW, ix = (q % HROW) - 1, pr = pr_lo + r;
-        const int b = pr / (H + 1), rr = pr - b * (H + 1);
+        const int q = ps + 32 * i, r = q / HROW, ix = (q % HROW) - 1;
+        const bool wrap = rr_lo + r >= H + 1;
+        const int b = b_lo + (wrap ? 1 : 0), rr = rr_lo + r - (wrap ? H + 1 : 0);
         const bool ok = r < RMAX && rr != 0 && b < nimg && (unsigned)ix < (unsigned)W;
         const int pix = ok ? (b * H + rr - 1) * W + ix : 0;
         roff[i] = (unsigned)pix * ((unsigned)p.a_ld * 4u) + (unsigned)l8 * 16u;
@@ -1895,6 +1904,7 @@ static int g_bf3_slots = 4;            // codes 114 / 115: input slots in flight
                                        //  asm load is garbage - that build hung the kernel; build.py now refuses any spilling kernel)
 static int g_bf3_producers = 8;        // codes 112 / 113: producer waves of the f16x2 on-the-fly-operand kernel: 4 / 8 (default)
 #ifdef DIC_EXPERIMENTS
+static int g_bf3_halo56 = 0;           // parked: 3x3 convolutions of 56x56 maps (64 or n x 128 output channels) with the on-the-fly operand on the LDS-halo kernel (codes 126 / 127)
 static int g_bf3_ws256_bn = 0;         // parked: on-the-fly operand (no residual, no copy) on the 256x128 kernel (codes 106 / 107)
 static int g_bf3_stages = 2;           // ring depth of the 128-wide variants (42 / 43)
 static int g_bf3_ws = 1;               // codes 76 / 77: persistent kernel in its warp-specialised form on / off
@@ -1903,7 +1913,7 @@ static int g_bf3_bn_ablate = 0;        // on-the-fly-operand kernel, timing only
 static int g_bf3_ws256_ablate = 0;     // 256x128 kernel (f16x2, planes), timing only: 1 = no DMA in the loop, 2 = no tile stores, 3 = neither, 4 = no fragment reads (44..47)
 static int g_bf3_halo_bna_ablate = 0;  // LDS-halo kernel, on-the-fly form, timing only (wrong results): bit 0 = no weight DMA in the loop, bit 1 = no input loads / transform in the loop (64..66)
 #else
-constexpr int g_bf3_stages = 2, g_bf3_ws = 1, g_bf3_ablate = 0;
+constexpr int g_bf3_stages = 2, g_bf3_ws = 1, g_bf3_ablate = 0, g_bf3_halo56 = 0;
 #endif
 template <int AK, int TM, int TN>
 static void launch_bf3_variant(const Bf3Params& p, int blocks, hipStream_t st) {
@@ -1944,6 +1954,7 @@ int gemm_bf3_force_tile(int code) {      // 0 = accepted, -1 = unknown in this b
   if (code == 120 || code == 121) { g_bf3_halo_ilv = code - 120; return 0; }               // LDS-halo kernel, on-the-fly form: fragment reads in a block / interleaved with the MFMAs (default)
   if (code == 118 || code == 119) { g_bf3_wgrad_persist = code - 118; return 0; }          // weight gradients: 64x64 tiles with the caller's K split / persistent 128x128 kernel, every tile in K slices (default)
 #ifdef DIC_EXPERIMENTS
+  if (code == 126 || code == 127) { g_bf3_halo56 = code - 126; return 0; }            // parked: LDS-halo kernel for 56x56 maps (on-the-fly operand form): never (default) / by policy
   if (code == 106 || code == 107) { g_bf3_ws256_bn = code - 106; return 0; }        // parked: conv3-style on-the-fly operand (no residual, no copy) on the 256x128 kernel: never (default) / by policy
   if (code == 110 || code == 111) { conv1x1_astat_switch(code - 110); return 0; }    // parked: conv3 (K = 128 / 256, f16x2) on the A-stationary kernel: never (default) / by shape
   if (code == 71 || code == 72) { g_bf3_persist_policy = code - 70; return 0; }
@@ -1994,7 +2005,11 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   //  out of the buffer's range and load as zeros, the epilogue's column guard drops them; twice the matrix work of a kernel that runs
   //  at a seventh of the matrix pipe, in exchange for the 820-MB pass that would otherwise write that block output as planes)
   const bool narrow_bn = g_bf3_narrow_bn != 0 && p.a_raw && p.N == 64 && p.A.kind == OPK_ROWK && p.fmt == 1;
-  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && (p.N % 128 == 0 || narrow_bn) && (plain_ep || g_bf3_ws) && buf_ok;
+  // (64 output channels on the LDS-halo kernel for 56x56 maps - layer 1's conv2 - in the same way)
+  const bool halo56 = g_bf3_halo56 != 0 && p.A.kind == OPK_IM2COL && p.A.g.H == 56 && p.A.g.W == 56 && p.a_raw && p.fmt == 1 && !p.a_res && !p.a_out &&
+                      p.A.g.C <= kHaloBnTab && (p.N == 64 || p.N % 128 == 0);
+  const bool narrow = narrow_bn || (halo56 && p.N == 64);
+  const bool persist_ok = splitk <= 1 && !p.ep.row_map && !p.ep.C2 && p.K > BK3 && (p.N % 128 == 0 || narrow) && (plain_ep || g_bf3_ws) && buf_ok;
   const long long t22 = (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
   const int rounds22 = (int)((t22 + g_bf3_persist_grid - 1) / g_bf3_persist_grid);
   double fill22 = (double)t22 / ((double)rounds22 * g_bf3_persist_grid);      // how evenly the tiles divide among the CUs
@@ -2052,7 +2067,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
   // (28x28 maps - ResNet layer 2 - only in the form that takes the raw input and forms the activation in the producer waves, f16x2)
   const bool halo28 = g_bf3_halo28 != 0 && cg.H == 28 && cg.W == 28 && p.a_raw && p.fmt == 1 && !p.a_res && !p.a_out && cg.C <= kHaloBnTab;
   const bool halo = g_bf3_halo != 0 && g_bf3_force == 0 && persist_ok && plain_ep && (t22 >= 128 || g_bf3_halo == 2) && p.A.kind == OPK_IM2COL && p.A.paired && cg.KH == 3 && cg.KW == 3 &&
-                    cg.stride == 1 && cg.pad == 1 && ((cg.H == 14 && cg.W == 14) || halo28) && cg.nchw == 0 && cg.C % BK3 == 0 &&
+                    cg.stride == 1 && cg.pad == 1 && ((cg.H == 14 && cg.W == 14) || halo28 || halo56) && cg.nchw == 0 && cg.C % BK3 == 0 &&
                     p.M % (cg.H * cg.W) == 0 && p.K == 9 * cg.C;
   if (halo) persist = true;
   if (persist) { tmv = 2; tnv = 2; }
@@ -2102,7 +2117,7 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       p.tail_first_tile = 0; p.tail_split = few_sp; p.tail_ws = tail_ws;
       p.few_remap = g_bf3_few_remap;
     } else
-    if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4 && !narrow_bn) {      // (the fix-up works on whole 64x64 quadrants of N % 128 == 0)
+    if (g_bf3_remainder_split && tail_ws && (plain_ep || !halo) && fullr >= 1 && r > 0 && units >= 4 && !narrow) {      // (the fix-up works on whole 64x64 quadrants of N % 128 == 0)
       // tail_ws holds tail_ws_slabs slabs of [64][64] floats (kGemmTailWsBytes = 256 for callers of the C ABI, 1024 inside the
       // ResNet workspace); a piece writes four (one per consumer wave): r * sp <= slabs / 4
       const int kSlabs = tail_ws_slabs;
@@ -2144,6 +2159,10 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
     if (p.a_raw && (g_bf3_bn_ablate & 2)) p.a_out = nullptr;
 #endif
     if (p.fmt == 1) {
+#ifdef DIC_EXPERIMENTS
+      if (halo_bna && cg.W == 56) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 58, 7, 1>), dim3(grid), dim3(512), 0, st, p);
+      else
+#endif
       if (halo_bna && cg.W == 28 && g_bf3_halo_ilv) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo_bna && cg.W == 28) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9>), dim3(grid), dim3(512), 0, st, p);
 #ifdef DIC_EXPERIMENTS

@@ -259,3 +259,18 @@ def test_conv1x1_on_the_fly_operand_on_the_256x128_kernel(lib, M, Cin, CO):
         yd, st = out[code][0].double().cpu(), out[code][1]
         tol = 1e-4 * sc * max(1.0, M / 12544)
         assert torch.allclose(st[0], yd.sum(0), rtol=1e-5, atol=tol) and torch.allclose(st[1], (yd * yd).sum(0), rtol=1e-5, atol=tol)
+
+
+@pytest.mark.parametrize("B,Cin,CO", [(64, 64, 64), (3, 64, 64), (2, 32, 128), (5, 64, 64)])
+def test_conv3x3_halo_kernel_for_56x56_maps(lib, B, Cin, CO):
+    """Round 4, parked (switch 127): the LDS-halo 3x3 kernel with the on-the-fly operand in a 7-row x 58-pixel geometry for ResNet layer 1
+    (64 -> 64 channels on half of the 128-column tile).  Same checks as the product's 14x14 / 28x28 forms - planes route at rounding
+    level, fp64, BatchNorm partials, ragged tiles, repeated launches, the overflow guard, bit-identity of the two fragment-read
+    schedules - by running the product test's body on this geometry.  Correct, and no faster than the planes pass + gathered kernel it
+    would replace (110 us against 17 + 85; csrc/gemm_bf3.hip)."""
+    from tests.test_gemm_gpu import test_conv3x3_halo_kernel_with_on_the_fly_operand as body
+    try:
+        assert lib.dic_debug_force_staged_gemm(127) == 0
+        body(lib, B, Cin, CO, 56)
+    finally:
+        lib.dic_debug_force_staged_gemm(126)
