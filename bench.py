@@ -92,8 +92,8 @@ def profile_step(trainer, args_step):
             kind = "on-the-fly BatchNorm operand" if a == 6 else KIND_NAMES[a]
             if tcode >= 4:                                  # 128x128: persistent warp-specialised / LDS-halo 3x3 (4, 7, 8: parked forms, experiments library only)
                 name, rname = {4: (f"gemm_bf3_pipe_kernel<{kind}>", f"gemm_bf3_pipe_kernel<{a}, "),
-                               5: (f"gemm_bf3_persist_ws_kernel<{kind}>", f"gemm_bf3_persist_ws_kernel<{a}, 0, 3, {int(f16)}>"),
-                               6: ("conv3x3_bf3_halo_kernel", f"conv3x3_bf3_halo_kernel<0, {int(f16)}>"),
+                               5: (f"gemm_bf3_persist_ws_kernel<{kind}>", f"gemm_bf3_persist_ws_kernel<{a}, 0, 3, {int(f16)},"),      # (+ producer waves, slots, loop form)
+                               6: ("conv3x3_bf3_halo_kernel", f"conv3x3_bf3_halo_kernel<0, {int(f16)},"),
                                7: (f"gemm_bf3_persist_ws256_kernel<{kind}>", f"gemm_bf3_persist_ws256_kernel<{a}"),
                                8: (f"gemm_bf3_persist_kernel<{kind}>", f"gemm_bf3_persist_kernel<{a}"),
                                9: ("conv1x1_astat_bn_kernel (A-stationary conv3, BatchNorm-apply fused)", "conv1x1_astat_bn_kernel<")}[tcode]
