@@ -17,10 +17,13 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--fmt", type=int, default=0, help="operand format: 0 = bf16x3, 1 = f16x2")
 ap.add_argument("--switches", default="", help="comma-separated dic_debug_force_staged_gemm codes")
+ap.add_argument("--persist-grid", type=int, default=0, help="dic_conv_persistent_grid (0 = library default)")
 ap.add_argument("--only", default="", help="run only the shapes whose name contains this")
 ap.add_argument("--rotate", type=int, default=1, help="cycle through this many input / output buffer sets (> 256 MiB in total: no launch finds its operands in the Infinity Cache)")
 a = ap.parse_args()
 lib = _lib.load()
+if a.persist_grid:
+    check(lib.dic_conv_persistent_grid(a.persist_grid), "persistent grid")
 for code in filter(None, a.switches.split(",")):
     assert lib.dic_debug_force_staged_gemm(int(code)) == 0, code
 DEV = "cuda:0"
