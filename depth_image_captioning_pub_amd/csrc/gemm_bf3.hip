@@ -2166,12 +2166,12 @@ static int launch_bf3(Bf3Params p, hipStream_t st, float* tail_ws, int splitk = 
       if (halo_bna && cg.W == 28 && g_bf3_halo_ilv) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo_bna && cg.W == 28) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 32, 9>), dim3(grid), dim3(512), 0, st, p);
 #ifdef DIC_EXPERIMENTS
-      else if (halo_bna && g_bf3_halo_bna_ablate == 1) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<1, 1, true>), dim3(grid), dim3(512), 0, st, p);
-      else if (halo_bna && g_bf3_halo_bna_ablate == 2) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<2, 1, true>), dim3(grid), dim3(512), 0, st, p);
-      else if (halo_bna && g_bf3_halo_bna_ablate == 3) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<3, 1, true>), dim3(grid), dim3(512), 0, st, p);
-      else if (halo_bna && g_bf3_halo_bna_ablate == 4) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<4, 1, true>), dim3(grid), dim3(512), 0, st, p);
-      else if (halo_bna && g_bf3_halo_bna_ablate == 8) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<8, 1, true>), dim3(grid), dim3(512), 0, st, p);
-      else if (halo_bna && g_bf3_halo_bna_ablate == 12) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<12, 1, true>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 1) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<1, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 2) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<2, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 3) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<3, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 4) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<4, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 8) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<8, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
+      else if (halo_bna && g_bf3_halo_bna_ablate == 12) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<12, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
 #endif
       else if (halo_bna && g_bf3_halo_ilv) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true, 16, 13, 1>), dim3(grid), dim3(512), 0, st, p);
       else if (halo_bna) hipLaunchKernelGGL((conv3x3_bf3_halo_kernel<0, 1, true>), dim3(grid), dim3(512), 0, st, p);
