@@ -131,3 +131,24 @@ def test_product_library_holds_no_parked_or_probe_code():
     # (two forms of its computing waves' loop: fragment reads in a block / interleaved, switches 120 / 121; no ablation, no other operand kind)
     assert ws256 and all(w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1ELb0ELi0ELi0EEEvNS_9Bf3ParamsE") or
                          w.endswith("gemm_bf3_persist_ws256_kernelILi0ELi1ELb0ELi0ELi1EEEvNS_9Bf3ParamsE") for w in ws256), ws256
+
+
+def test_bench_finds_its_contraction_kernels_in_the_committed_pmc_summary():
+    """bench.py fills `roofline.traffic` from the newest profiles/r*_pmc_per_kernel.json by kernel name.  The key it derives from the
+    profile key of a launch must stay a prefix of the kernel's demangled name when the kernel gains template parameters: in r04c the key
+    ended in '>' and matched nothing (`traffic: null` in the line).  Checked against the committed summary: the three largest
+    contraction kernels of the forward are found, with a plausible number of bytes."""
+    import glob
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_per_kernel.json")))[-1]
+    names = [r["kernel"] for r in json.load(open(newest))]
+    for key in ("gemm_bf3_persist_ws_kernel<6, 0, 3, 1,", "conv3x3_bf3_halo_kernel<0, 1,", "gemm_bf3_persist_ws256_kernel<0"):
+        assert any(key in n for n in names), (key, os.path.basename(newest))
+        traffic, _ = bench.pmc_for(key, 64)
+        assert traffic is not None and 1e6 < traffic < 2e9, (key, traffic)
+    # and the keys are the ones bench.py builds (source check: no closing '>' behind the format digit)
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'f"gemm_bf3_persist_ws_kernel<{a}, 0, 3, {int(f16)},"' in src and 'f"conv3x3_bf3_halo_kernel<0, {int(f16)},"' in src
