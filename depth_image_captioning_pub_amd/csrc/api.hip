@@ -4,7 +4,7 @@
 
 using namespace dic;
 
-namespace dic { void resnet_fuse_bn_operand(int mask); void resnet_fuse_bn_halo(int on); void resnet_fuse_res_bn(int on); void depth_encoder_l1_sparse(int on); void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n);
+namespace dic { void resnet_fuse_bn_operand(int mask); void resnet_fuse_bn_halo(int on); void resnet_fuse_res_bn(int on); void depth_encoder_l1_sparse(int on); void bn_finalize_two_level_rows(int rows); void resnet_debug_fused_tail_bn(int on); void conv1_depth_debug_blocks(int n);
                 void depth_encoder_f16x2(int on); }
 #ifdef DIC_EXPERIMENTS
 namespace dic { void decoder_debug_persistent(int on); void decoder_persist_debug_buffer(unsigned long long* p); void decoder_persist_debug_placement(int p);
@@ -59,6 +59,7 @@ int dic_debug_force_staged_gemm(int on) {
   if (on >= 100 && on <= 104) { dic::resnet_fuse_bn_operand(on == 104 ? -1 : on - 100); return 0; }
   if (on == 98 || on == 99) { dic::resnet_fuse_res_bn(on - 98); return 0; }           // downsample-branch BatchNorm inside the on-the-fly 1x1 kernel: never / yes (default)
   if (on == 108 || on == 109) { dic::resnet_fuse_bn_halo(on - 108); return 0; }       // conv1 -> conv2 BatchNorm-apply inside the halo kernel: never / by shape (default)
+  if (on == 182 || on == 183) { dic::bn_finalize_two_level_rows(on == 182 ? 512 : 1024); return 0; }   // BatchNorm finalize in two launches above 512 / 1024 (default) rows of partials
   if (on == 180 || on == 181) { dic::depth_encoder_l1_sparse(on - 180); return 0; }   // depth encoder layer-1 backward: dense / sparse (default)
   if (on == 116 || on == 117) { dic::depth_encoder_f16x2(on - 116); return 0; }      // depth encoder conv2 / conv3: bf16x3 / f16x2 (default)
 #ifdef DIC_EXPERIMENTS

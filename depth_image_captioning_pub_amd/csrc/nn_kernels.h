@@ -28,6 +28,7 @@ int f16_scale_finish(F16Scale s, hipStream_t st);                               
 // train mode: reduce the conv epilogue's per-tile partial sums [mtiles][2][C] (fp64), produce
 // scale/shift (+ saved mean/invstd) and update the running statistics (unbiased variance).
 // `red`: fp64 scratch of bn_finalize_ws_doubles(max mtiles, C) doubles.
+void bn_finalize_two_level_rows(int rows);      // partial-sum rows above which bn_finalize_train takes two launches (default 1024; 512 until round 4)
 size_t bn_finalize_ws_doubles(long long max_mtiles, int C);
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, BnBuf out, double* red,

@@ -168,13 +168,17 @@ __global__ void __launch_bounds__(256) bn_finalize_from_slices_kernel(const doub
   }
 }
 
+static int g_bn_two_level_rows = 1024;
+void bn_finalize_two_level_rows(int rows) { g_bn_two_level_rows = rows; }
 size_t bn_finalize_ws_doubles(long long max_mtiles, int C) {
   return (size_t)ceil_div(max_mtiles, kBnSliceTiles) * 2 * (size_t)C + 16;
 }
 
 int bn_finalize_train(const float* partial, int mtiles, long long count, int C, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, BnBuf out, double* red, hipStream_t st, unsigned* status) {
-  if (mtiles > 512 && red != nullptr) {
+  // (two launches only where one would crawl: ResNet layer 1 has 3136 rows of partials; layer 2's 784 go through the single kernel -
+  //  four batches of loads per thread, ~7 us against 5 + 5.4 for the pair; switch g_bn_two_level_rows for the A/B)
+  if (mtiles > g_bn_two_level_rows && red != nullptr) {
     const int slices = ceil_div(mtiles, kBnSliceTiles);
     hipLaunchKernelGGL(bn_stats_slice_kernel, dim3(ceil_div(C, 32), slices), dim3(256), 0, st, partial, mtiles, C, red);
     hipLaunchKernelGGL(bn_finalize_from_slices_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)red,

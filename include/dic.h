@@ -441,6 +441,8 @@ int dic_gather_rows(const float* table, const int64_t* idx, int n, long long row
  *   112 113      mode 2: producer waves of the on-the-fly-operand 1x1 kernel: four / eight (default)
  *   114 115      ... input slots each of its producer waves keeps in flight: four (default) / six
  *   116 117      depth encoder conv2 / conv3 (forward and both gradients): exact bf16x3 split / f16x2 with device-resident scales (default)
+ *   182 183      train-mode BatchNorm finalize in two launches (slice sums, then the statistics) above 512 / 1024 (default) rows of partial
+ *                sums: ResNet layer 2's 784 rows take the single kernel
  *   180 181      backward of the depth encoder's first layer: three passes over its full-size map and gradient / sparse form without either
  *                (default; csrc/depth_layer1.hip)
  *   120 121      mode 2: computing waves of the 128x128 kernels (LDS-halo 3x3 in its on-the-fly form, persistent 1x1 / gathered) read their

@@ -89,15 +89,15 @@ def test_loader_fails_loudly_when_library_missing(monkeypatch, tmp_path):
 
 def test_unknown_debug_switch_is_rejected():
     """The kernel-selection switches are process-global state (include/dic.h): an unknown code must be an error, not a silent
-    change of some other switch (round 2: code 182 fell through to the exact-fp32 kernel selector).  The product library only
+    change of some other switch (round 2: a then-unknown code, 182, fell through to the exact-fp32 kernel selector).  The product library only
     knows the codes its tests use; ablations and parked kernels (23 / 26 / 77 bf16x3 forms, 50..53 ablations, 141 persistent
     decoder loop, 1 register-staged kernel everywhere) belong to the experiments build.  No GPU call involved."""
     lib = ctypes.CDLL(build.build())
     lib.dic_last_error.restype = ctypes.c_char_p
-    for code in (9999, 182, -5, 29, 23, 26, 77, 51, 141, 1, 131, 122, 64, 68, 110, 111, 106, 107):
+    for code in (9999, 184, -5, 29, 23, 26, 77, 51, 141, 1, 131, 122, 64, 68, 110, 111, 106, 107):
         assert lib.dic_debug_force_staged_gemm(code) != 0, code
         assert b"unknown" in lib.dic_last_error()
-    for code in (11, 21, 24, 70, 75, 74, 90, 81, 100, 101, 102, 103, 112, 115, 116, 118, 108, 92, 94, 96, 98, 180, 120, 20, 78, 76, 73, 79, 91, 104, 80, 113, 114, 117, 119, 109, 93, 95, 97, 99, 181, 121):  # (ending on the defaults)
+    for code in (11, 21, 24, 70, 75, 74, 90, 81, 100, 101, 102, 103, 112, 115, 116, 118, 108, 92, 94, 96, 98, 180, 120, 182, 20, 78, 76, 73, 79, 91, 104, 80, 113, 114, 117, 119, 109, 93, 95, 97, 99, 181, 121, 183):  # (ending on the defaults)
         assert lib.dic_debug_force_staged_gemm(code) == 0, code
 
 

@@ -392,6 +392,27 @@ def test_resnet_forward_with_interleaved_fragment_reads_is_bit_identical(lib):
     assert torch.equal(out[120][0], out[121][0]) and torch.equal(out[120][1], out[121][1])
 
 
+def test_resnet_forward_single_launch_batchnorm_finalize_for_layer2_is_bit_identical(lib):
+    """Round 4: train-mode BatchNorm statistics of a layer with 513..1024 rows of partial sums (ResNet layer 2 at batch 64: 784) are
+    finalized by ONE launch (switch 183, default) instead of slice sums + finalize (182).  Both add the same fp32 partials in fp64 - where
+    sums of a few hundred fp32 values are exact whatever the order - so features and running statistics agree bit for bit."""
+    w = syn.resnet152_weights(seed=127)
+    imgs = syn.rgb_images(64, seed=125).to(DEV)
+    out = {}
+    try:
+        for code in (182, 183):
+            assert lib.dic_debug_force_staged_gemm(code) == 0
+            wd = _dev(w)
+            runner = native.ResNetRunner(wd, conv_mode="f16x2")
+            y = runner.forward(imgs, train_bn=True, compact=True)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and int(runner.status_word().item()) == 0
+            out[code] = (y.clone(), torch.cat([wd[k].flatten() for k in sorted(wd) if "running" in k]).clone())
+    finally:
+        lib.dic_debug_force_staged_gemm(183)
+    assert torch.equal(out[182][0], out[183][0]) and torch.equal(out[182][1], out[183][1])
+
+
 def test_layer1_kernels_reproducible_next_to_lds_heavy_kernels(lib):
     """The packed-FMA layer-1 kernels of the depth encoder (csrc/conv1_depth.hip), called alone through the library, repeated
     on identical inputs while a bf16x3 ResNet forward on its round-1 gather kernels (debug codes 70 75: three LDS-heavy
